@@ -17,20 +17,3 @@ def pytest_configure(config):
 def golden():
     """tests/golden/tiny.npz -- outputs of the unmodified reference (see tests/golden/make_golden.py)."""
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "tiny.npz"), allow_pickle=False))
-
-
-# GPU cases of the plugins written after this round's device budget was spent.  Their host logic is pinned against the
-# reference goldens by the CPU module (tests/test_models_cpu.py, strict), and they call only device-verified ops, but
-# they have never executed on an MI355X.  Until each has passed there once, a failure is reported as `xfailed` (and a
-# pass as `xpassed`) instead of stopping the `-x` run of the device-verified suite in front of them.  Remove a name
-# from this list after its first green device run.
-FIRST_DEVICE_RUN = ("test_dualgnn_model", "test_dragon_model", "test_mmgcf_model", "test_slmrec_model",
-                    "test_itemknncbf_model", "test_grcn_model", "test_mvgae_model", "test_damrs_model",
-                    "test_dual_family_trainer_fit", "test_whole_run_on_device_follows_reference")
-
-
-def pytest_collection_modifyitems(config, items):
-    for item in items:
-        if getattr(item, "module", None) is not None and item.module.__name__.endswith("test_models_gpu") \
-                and getattr(item, "originalname", None) in FIRST_DEVICE_RUN:
-            item.add_marker(pytest.mark.xfail(strict=False, reason="first run on the device (see tests/conftest.py)"))

@@ -947,8 +947,24 @@ def test_itemknncbf_model(tmp_path, golden):
     res = trainer.evaluate(valid_data)
     keys = [str(k) for k in g["metric_keys"]]
     # most of a score row is exactly 0 (items no neighbour list reaches) and short histories put such items inside
-    # the top-50: their order is whatever torch.topk does with ties, which differs between the CPU and the device
-    np.testing.assert_allclose([res[k] for k in keys], g["metrics"], atol=0.03 if USE_GPU else 1e-4)
+    # the top-50: WHICH zero-score items fill the tail is whatever torch.topk does with ties (unspecified; differs
+    # between its CPU and device implementations: first device run, round 2: Recall@50 0.6075 vs 0.5525 on 200 users).
+    # What is pinned on the device is therefore everything ties cannot move: the masked score rows give the same
+    # top-50 SCORE VALUES as the reference's score matrix, and every metric whose cut-off lies above the tie plateau
+    # (the cut-offs 5/10/20 agreed to 1e-4 in that run) -- metrics on the CPU, where torch.topk is the reference's, exactly.
+    if USE_GPU:
+        users, mask = next(iter(valid_data))
+        for _ in valid_data:
+            pass
+        sc = model.full_sort_predict([users, mask]).clone()
+        sc[mask[0], mask[1]] = -1e10
+        ref = torch.as_tensor(g["scores_matrix"])[users.cpu()].clone()
+        ref[mask[0].cpu(), mask[1].cpu()] = -1e10
+        close(torch.topk(sc, 50, dim=-1)[0], torch.topk(ref, 50, dim=-1)[0].numpy(), rtol=1e-4, atol=1e-5)
+        above = [j for j, k in enumerate(keys) if not k.endswith("@50")]
+        np.testing.assert_allclose([res[keys[j]] for j in above], g["metrics"][above], atol=5e-3)
+    else:
+        np.testing.assert_allclose([res[k] for k in keys], g["metrics"], atol=1e-4)
     assert float(model.calculate_loss(None)) == 0.0 and [n for n, _ in model.named_parameters()] == ["dummy_embeddings"]
     config["epochs"] = 1
     trainer.fit(train_data, valid_data=valid_data, test_data=valid_data, verbose=False)
@@ -1120,7 +1136,9 @@ def test_dual_family_trainer_fit(tmp_path, golden, name, extra):
 # they follow the CPU reference's trajectory up to fp32 summation order (and, where an item graph is built from the
 # features by the device top-K, up to a near-tie neighbour)
 DEVICE_RUNS = ("LightGCN", "BPR", "VBPR", "LATTICE", "LATTICE+mf", "MGCN", "DualGNN", "DRAGON", "GRCN", "SLMRec", "DAMRS",
-               "FREEDOM+nodrop", "MMGCF+norm", "BPR+clip", "LightGCN+cfg", "VBPR+stop", "ItemKNNCBF")
+               "FREEDOM+nodrop", "MMGCF+norm", "BPR+clip", "LightGCN+cfg", "VBPR+stop")
+# (ItemKNNCBF's whole run is CPU-only: its top-50 tails are exact-zero ties whose order torch.topk leaves unspecified,
+# see test_itemknncbf_model)
 
 
 @pytest.mark.parametrize("run", DEVICE_RUNS)
@@ -1134,6 +1152,6 @@ def test_whole_run_on_device_follows_reference(tmp_path, golden, run):
     assert len(losses) == len(ref["losses"])
     if len(losses):
         np.testing.assert_allclose(losses, ref["losses"], rtol=5e-3)
-    slack = 0.05 if run == "ItemKNNCBF" else 0.03          # a few near-tie ranks among 200 users (exact-zero ties: ItemKNNCBF)
+    slack = 0.03          # a few near-tie ranks among 200 users
     np.testing.assert_allclose(valid, ref["valid"], atol=slack)
     np.testing.assert_allclose(test, ref["test"], atol=slack)
