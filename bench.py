@@ -340,9 +340,9 @@ def extra_baby(dev):
     except Exception as ex:
         out["cpu_baseline_full_eval"] = {"error": repr(ex)}
     with torch.no_grad():   # last: its 557 MB score block evicts everything the measurements above keep in cache
-        os.environ["MMREC_TOPK_FILTER"] = "0"       # the materialised fp32-MFMA path, for comparison
-        out["baby_score_topk_materialised_ms"] = timeit(lambda: hip_ops.score_topk(U, I, 50, rp, col), reps=10, warm=2) * 1e3
-        del os.environ["MMREC_TOPK_FILTER"]
+        # the materialised fp32-MFMA path, for comparison
+        out["baby_score_topk_materialised_ms"] = timeit(lambda: hip_ops.score_topk(U, I, 50, rp, col, use_filter=False),
+                                                        reps=10, warm=2) * 1e3
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 4
+#define MMREC_ABI_VERSION 5
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -178,14 +178,17 @@ int mmrec_gemm_nt_f32(const float* A, const float* B, const float* bias, float* 
  * only appear when fewer than k candidates are unmasked.  workspace: mmrec_topk_workspace_bytes.
  * Scores are fp32 dot products in every implementation behind this entry point: kd == 64 with >= 4096 candidates
  * runs an fp16 matrix-core FILTER with a proven error bound and rescores the ~k survivors per query exactly
- * (topk_filter.hip; the environment variable MMREC_TOPK_FILTER=0, read per call, keeps the materialised fp32 path for
- * A/B measurements), the other shapes materialise fp32-MFMA score blocks inside the workspace (topk.hip).
+ * (topk_filter.hip; `flags & MMREC_TOPK_NO_FILTER` keeps the materialised fp32 path for A/B measurements -- an
+ * ARGUMENT since ABI 5: the library reads no environment and keeps no state), the other shapes materialise
+ * fp32-MFMA score blocks inside the workspace (topk.hip).  Unknown flag bits: MMREC_ERR_BAD_ARG.
  * ---------------------------------------------------------------------------------------------- */
 #define MMREC_TOPK_MAX 64
+#define MMREC_TOPK_NO_FILTER 1
 size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd, int32_t k);
 int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc, int32_t kd,
                          const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
-                         int64_t* out_idx, float* out_val, void* workspace, mmrec_stream_t stream);
+                         int64_t* out_idx, float* out_val, void* workspace, int32_t flags,
+                         mmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * P1  graph build on device.

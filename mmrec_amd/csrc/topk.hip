@@ -6,7 +6,7 @@
 // Implementations behind mmrec_score_topk_f32:
 //  * kd == 64 with >= 4096 candidates (every full-sort evaluation of the Amazon shapes): fp16 matrix-core FILTER +
 //    exact fp32 refinement, topk_filter.hip (0.165 ms on the Baby evaluation against 0.41 ms for the form below);
-//  * kd == 64, fewer candidates (or MMREC_TOPK_FILTER=0): MATERIALISED -- the score block of up to 8 GB worth of
+//  * kd == 64, fewer candidates (or flags & MMREC_TOPK_NO_FILTER): MATERIALISED -- the score block of up to 8 GB worth of
 //    queries is written once by the output-bound streaming GEMM of mfma_stream.h (which also emits
 //    <= 384 group maxima per query), then `select_topk_kernel` masks, bounds, sweeps and sorts each
 //    row on a wave of its own.  See the comment above that kernel.  Baby shape: 0.42 ms against
@@ -611,8 +611,8 @@ extern "C" size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd,
     if (p.materialise) {  // [Ct (kd == 64 only)] [S block] [group maxima]
         const size_t b = (kd == 64 ? al256((size_t)kd_pad * ldc * 4) : 0) + al256((size_t)p.qb_rows * ldc * 4) +
                          al256((size_t)p.qb_rows * GEMM64_MAX_GROUPS * 4);
-        // either path may serve the call (MMREC_TOPK_FILTER is read at launch): size for both
-        const size_t f = topk64_filter_applicable(nq, nc, kd, k, false) ? topk64_filter_workspace_bytes(nq, nc, k) : 0;
+        // either path may serve the call (`flags` of mmrec_score_topk_f32 decides): size for both
+        const size_t f = topk64_filter_applicable(nq, nc, kd, k) ? topk64_filter_workspace_bytes(nq, nc, k) : 0;
         return b > f ? b : f;
     }
     size_t b = al256((size_t)kd_pad * ldc * 4);               // Ct
@@ -625,8 +625,9 @@ extern "C" size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd,
 extern "C" int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc,
                                     int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col,
                                     int32_t k, int64_t* out_idx, float* out_val, void* workspace,
-                                    mmrec_stream_t stream) {
+                                    int32_t flags, mmrec_stream_t stream) {
     if (nq < 0 || nc < 0 || kd <= 0 || (kd & 3)) return MMREC_ERR_UNSUPPORTED;
+    if (flags & ~MMREC_TOPK_NO_FILTER) return MMREC_ERR_BAD_ARG;
     if (k <= 0 || k > MMREC_TOPK_MAX || k > nc) return MMREC_ERR_BAD_ARG;
     if (nq == 0) return 0;
     if (!Q || !C || !out_idx || !workspace) return MMREC_ERR_BAD_ARG;
@@ -635,7 +636,7 @@ extern "C" int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, 
     const int kd_pad = pad_to(kd, 64), ldc = pad_to(nc, 256), ldq = pad_to(nq, 32);
     char* ws = static_cast<char*>(workspace);
     hipStream_t s = mmrec_stream(stream);
-    if (p.materialise && topk64_filter_applicable(nq, nc, kd, k, true))
+    if (p.materialise && !(flags & MMREC_TOPK_NO_FILTER) && topk64_filter_applicable(nq, nc, kd, k))
         return topk64_filter_launch(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, s);
     if (p.materialise) {
         float* Ct = nullptr;

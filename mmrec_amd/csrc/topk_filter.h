@@ -2,9 +2,9 @@
 #pragma once
 #include "common.h"
 
-// true when mmrec_score_topk_f32 should take the filter path for this shape (check_env: honour the
-// MMREC_TOPK_FILTER=0 switch, read per call, that keeps the materialised path for A/B measurements)
-bool topk64_filter_applicable(int nq, int nc, int kd, int k, bool check_env);
+// true when the filter path can serve this shape (mmrec_score_topk_f32 takes it unless the caller passes
+// MMREC_TOPK_NO_FILTER in `flags`, which keeps the materialised path for A/B measurements)
+bool topk64_filter_applicable(int nq, int nc, int kd, int k);
 size_t topk64_filter_workspace_bytes(int nq, int nc, int k);
 // same contract as mmrec_score_topk_f32 (kd == 64): enqueues on `s`, never synchronises
 int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,

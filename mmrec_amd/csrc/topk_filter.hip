@@ -9,10 +9,14 @@
 // How:
 //  prep   candidates are CENTRED (c' = c - mean row: a per-query constant shift of all scores, no ranking
 //         changes, but the common component LightGCN-smoothed embeddings share no longer inflates the norms the
-//         error bound is stated in), queries and centred candidates are scaled by powers of two into fp16's
-//         normal range and rounded to fp16 (unit roundoff u = 2^-11).  Approximate score = fp16 x fp16 products
-//         accumulated in fp32 on v_mfma_f32_32x32x16_f16:  |approx - exact| <= (2u + u^2) sum|q_i||c'_i| +
-//         accumulation rounding <= eps_q := 1.0e-3 |q| max|c'| (Cauchy-Schwarz; a worst-case bound).
+//         error bound is stated in); every QUERY row is scaled by its own power of two (thresholds are per query,
+//         so a per-query scale changes no ranking; one global scale would push a query whose norm is 2^-30 of the
+//         largest one into fp16 subnormals, where the relative bound below no longer holds), the centred candidates
+//         by one power of two, both into fp16's normal range, and rounded to fp16 (unit roundoff u = 2^-11; an
+//         element that still lands below 2^-14 is rounded with ABSOLUTE error <= 2^-25).  Approximate score = fp16 x
+//         fp16 products accumulated in fp32 on v_mfma_f32_32x32x16_f16:  |approx - exact| <= (2u + u^2) sum|q_i||c'_i|
+//         + 2^-25 (sum|q_i| + sum|c'_i|) + accumulation rounding <= eps_q := 1.0e-3 |q| max|c'| + 2^-22 (|q| + max|c'|)
+//         (Cauchy-Schwarz, sum|x_i| <= 8 |x|; a worst-case bound for ANY input, tests/test_host_logic.py).
 //  pass 1 approximate scores of every (query, candidate), kept only as 32 running maxima per query and
 //         candidate range (lane = query: a group is one accumulator register of one half-wave) ->
 //         n_groups = 32 * ranges maxima per query.
@@ -35,7 +39,6 @@
 #include "topk_filter.h"
 #include "topk_sort.h"
 #include <limits.h>
-#include <stdlib.h>
 #include <type_traits>
 
 // tools/prof_topk_filter.py builds this file with an ablation mask (the library only ever uses 0):
@@ -66,16 +69,13 @@ __device__ __forceinline__ unsigned f2key(float f) {   // monotone: a < b  <=>  
 __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
-// stats[0..63] = column sums of C, stats[64] = key(max |q_ij|), stats[65] = key(max |c_ij|).  Grid: the row slabs
-// of Q first, then those of C (128 rows per workgroup).
-__global__ __launch_bounds__(256) void filter_stats_kernel(const float* __restrict__ Q, int nq, const float* __restrict__ C,
-                                                          int nc, float* __restrict__ stats) {
+// stats[0..63] = column sums of C, stats[65] = key(max |c_ij|) (queries are scaled row by row: nothing global to
+// collect for them).  Grid: the 128-row slabs of C.
+__global__ __launch_bounds__(256) void filter_stats_kernel(const float* __restrict__ C, int nc, float* __restrict__ stats) {
     __shared__ float4 s_sum[16][16];
     __shared__ float s_mx[4];
-    const int qb = (nq + 127) / 128;
-    const bool isq = (int)blockIdx.x < qb;
-    const float* X = isq ? Q : C;
-    const int n = isq ? nq : nc, r0 = (isq ? blockIdx.x : blockIdx.x - qb) * 128;
+    const float* X = C;
+    const int n = nc, r0 = blockIdx.x * 128;
     const int sub = threadIdx.x & 15, rr = threadIdx.x >> 4;
     float4 v[8];   // the thread's 8 rows, all loads in flight at once
 #pragma unroll
@@ -96,9 +96,8 @@ __global__ __launch_bounds__(256) void filter_stats_kernel(const float* __restri
     s_sum[rr][sub] = sum;
     __syncthreads();
     if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(stats) + (isq ? 64 : 65),
-                  f2key(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
-    if (!isq && threadIdx.x < 16) {
+        atomicMax(reinterpret_cast<unsigned*>(stats) + 65, f2key(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
+    if (threadIdx.x < 16) {
         float4 t = f4_zero();
         for (int j = 0; j < 16; ++j) t = f4_add(t, s_sum[j][threadIdx.x]);
         atomicAdd(stats + 4 * threadIdx.x + 0, t.x);
@@ -114,7 +113,7 @@ __device__ __forceinline__ float fp16_scale(float mx) {
     if (!(mx > 0.f)) return 1.f;
     int ex;
     frexpf(mx, &ex);            // mx = f * 2^ex, f in [0.5, 1)
-    return ldexpf(1.f, 13 - ex);
+    return ldexpf(1.f, min(13 - ex, 120));   // denormal-sized inputs: the scale itself must stay finite
 }
 
 // X [n][64] fp32 -> Xs [n_pad][8] uint4 = fp16(scale * (x - centre)), 8 halves per chunk, natural k order; rows >= n
@@ -125,8 +124,6 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
                                                             float* __restrict__ norm, unsigned* __restrict__ maxnorm_key) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int row = t >> 3, ch = t & 7;   // grid covers n_pad rows exactly (n_pad % 32 == 0)
-    const float amax = key2f(reinterpret_cast<const unsigned*>(stats)[CAND ? 65 : 64]);
-    const float scale = fp16_scale(CAND ? 2.f * amax : amax);   // |c - mean| <= 2 max|c|
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = 0.f;
@@ -139,6 +136,18 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] -= stats[ch * 8 + j] * inv;
         }
+    }
+    float scale;
+    if (CAND) {   // one scale for all candidates: |c - mean| <= 2 max|c|
+        scale = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[65]));
+    } else {      // a query row's own scale (the 8 threads of a row are 8 consecutive lanes)
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(x[j]));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 8));
+        scale = fp16_scale(mx);
     }
     unsigned hb[8];
     float ss = 0.f;
@@ -376,7 +385,8 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
         for (int j = 0; j < 8; ++j) c += __popcll(__ballot(key[j] >= trial));
         if (c >= rank) cur = trial;
     }
-    // eps in the scaled, centred units of the approximate scores: fp16 rounding of both operands (2u + u^2 and
+    // eps in the scaled (by the query's own and the candidates' power of two), centred units of the approximate
+    // scores: fp16 rounding of both operands (2u + u^2 and
     // the accumulation, 1.0e-3 of |q| max|c'|) plus the fp32 rounding of the EXACT scores the final kernel ranks by
     // (64 * 2^-24 of |q| max|c|, the uncentred norm: |c| <= |c'| + |mean|)
     float mu = lane < 64 ? stats[lane] / (float)nc : 0.f;
@@ -384,7 +394,9 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
     if (lane == 0) {
         const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[65]));
         const float cmax = key2f(*cmax_key);
-        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * (cmax + sc * sqrtf(mu)));
+        // + 2^-22 (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
+        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * (cmax + sc * sqrtf(mu))) +
+                          2.4e-7f * (qnorm[q] + cmax);
         thr[q] = key2f(cur) - 2.f * eps;
         flag[q] = 0;
     }
@@ -631,11 +643,8 @@ inline size_t al256f(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-bool topk64_filter_applicable(int nq, int nc, int kd, int k, bool check_env) {
-    if (kd != 64 || k > 64 || nc < F_MIN_NC || nc > 1000000 || nq < 1) return false;   // 16-bit ids inside a range
-    if (!check_env) return true;
-    const char* e = getenv("MMREC_TOPK_FILTER");
-    return !(e && e[0] == '0');
+bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
+    return kd == 64 && k <= 64 && nc >= F_MIN_NC && nc <= 1000000 && nq >= 1;   // 16-bit ids inside a range
 }
 
 size_t topk64_filter_workspace_bytes(int nq, int nc, int k) {
@@ -652,7 +661,7 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     uint4* Qs = reinterpret_cast<uint4*>(ws);          ws += al256f((size_t)p.nq_pad * 128);
     uint4* Cs = reinterpret_cast<uint4*>(ws);          ws += al256f((size_t)p.n_stages * 64 * 128);
     float* qnorm = reinterpret_cast<float*>(ws);       ws += al256f((size_t)p.nq_pad * 4);
-    float* stats = reinterpret_cast<float*>(ws);       // [0..63] column sums of C, [64] / [65] max |q| / |c| keys,
+    float* stats = reinterpret_cast<float*>(ws);       // [0..63] column sums of C, [65] max |c| key,
     unsigned* cmax = reinterpret_cast<unsigned*>(ws) + 66;   // [66] max |c'| key, [67] length of the slow queue
     int* n_flagged = reinterpret_cast<int*>(ws) + 67;  ws += 512;
     unsigned* gkeys = reinterpret_cast<unsigned*>(ws); ws += al256f((size_t)nq * p.n_groups * 4);
@@ -662,7 +671,7 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws);   // [nq][R][2][spr / 2]
     hipError_t e = hipMemsetAsync(stats, 0, 512, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nq, 128) + cdiv_i(nc, 128)), dim3(256), 0, s, Q, nq, C, nc, stats);
+    hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, stats);
     hipLaunchKernelGGL((filter_convert_kernel<false>), dim3(p.nq_pad * 8 / 256), dim3(256), 0, s, Q, nq, p.nq_pad, stats,
                        Qs, qnorm, (unsigned*)nullptr);
     hipLaunchKernelGGL((filter_convert_kernel<true>), dim3(p.n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc,

@@ -566,9 +566,13 @@ def mask_to_csr(mask, n_rows, device):
             torch.from_numpy(m[1][order].astype(np.int32)).to(device))
 
 
-def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False):
+TOPK_NO_FILTER = 1
+
+
+def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True):
     """top-k over candidates c of <Q[q], C[c]> per query with masked candidates at -1e10; never
-    materialises the score matrix.  Returns int64 [nq, k] sorted by score desc (ties: lower id)."""
+    materialises the score matrix.  Returns int64 [nq, k] sorted by score desc (ties: lower id).
+    use_filter=False keeps the materialised fp32 path where the fp16 filter would serve the call (A/B measurements)."""
     lib = _lib.load()
     Q = _chk(Q.contiguous(), torch.float32, "Q", 2)
     C = _chk(C.contiguous(), torch.float32, "C", 2)
@@ -585,7 +589,8 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False):
     val = torch.empty(nq, k, dtype=torch.float32, device=Q.device) if return_values else None
     ws = _ws(lib.mmrec_topk_workspace_bytes(nq, nc, kd, k), Q.device)
     _lib.check(lib.mmrec_score_topk_f32(_p(Q), _p(C), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
-                                        _p(idx), _p(val), _p(ws), _stream()), "score_topk")
+                                        _p(idx), _p(val), _p(ws), 0 if use_filter else TOPK_NO_FILTER, _stream()),
+               "score_topk")
     return (idx, val) if return_values else idx
 
 

@@ -463,7 +463,7 @@ def test_topk_filter_path_edge_cases(ops, dev, monkeypatch):
     """kd = 64, nc >= 4096: the fp16 filter + exact refinement path (topk_filter.hip) and its on-device slow
     queue.  (a) all scores tie and K > #unmasked for some queries: every list overflows -> streaming exact
     top-k, ties by lower id, masked items at -1e10 fill the tail; (b) random data, filter vs materialised
-    path (MMREC_TOPK_FILTER=0): same ids, scores equal to fp32 rounding; (c) tiny score gaps (1e-6 relative,
+    path (use_filter=False): same ids, scores equal to fp32 rounding; (c) tiny score gaps (1e-6 relative,
     far below the fp16 filter's error): the exact refinement still orders them."""
     nq, nc, k = 70, 4500, 20
     Q = np.ones((nq, 64), np.float32)
@@ -490,10 +490,8 @@ def test_topk_filter_path_edge_cases(ops, dev, monkeypatch):
     rp, col = ops.mask_to_csr(np.stack([key // nc, key % nc]), nq, dev)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("MMREC_TOPK_FILTER", mode)
-        i_, v_ = ops.score_topk(D(Qr, dev), D(Cr, dev), k, rp, col, return_values=True)
+        i_, v_ = ops.score_topk(D(Qr, dev), D(Cr, dev), k, rp, col, return_values=True, use_filter=mode == "1")
         out[mode] = (i_.cpu().numpy(), v_.cpu().numpy())
-    monkeypatch.delenv("MMREC_TOPK_FILTER")
     np.testing.assert_allclose(out["1"][1], out["0"][1], rtol=2e-6, atol=2e-6)
     assert np.mean(out["1"][0] == out["0"][0]) > 0.999
     # (c) candidates c0..c63 = base * (1 + j * 1e-6): gaps of ~1e-6 relative
@@ -503,6 +501,36 @@ def test_topk_filter_path_edge_cases(ops, dev, monkeypatch):
     Cg[100:164] = base[None, :] * (1.0 + np.arange(64, dtype=np.float32)[:, None] * 1e-6)
     Qg = np.tile(base, (nq, 1)).astype(np.float32)
     _topk_check(ops, dev, Qg, Cg, k, None, exact_gap=1e-6)
+    # (d) round-1 review: HETEROGENEOUS query norms.  With one global query scale a row 2^-30 below the largest one fell
+    # into fp16 subnormals, the filter's error bound no longer covered its rounding error and pass 2 could drop a true
+    # top-k item silently; queries are now scaled row by row.  Every row is checked in ITS OWN units (float64 scores).
+    nq, nc, k = 300, 6000, 50
+    Qh = (rng.standard_normal((nq, 64)) * 0.2).astype(np.float32)
+    for r, e in enumerate((-20, -24, -28, -30, -34, -40, -60, -100)):
+        Qh[r] *= np.float32(2.0) ** e
+    Qh[20] = 0.0                                    # all scores tie at 0: slow queue, lowest ids
+    Qh[21] *= np.float32(1e25)
+    Qh[22, 1:] *= np.float32(2.0) ** -30            # one dominant element
+    Ch = (rng.standard_normal((nc, 64)) * 0.2 + 0.5).astype(np.float32)     # common component: exercises the centring
+    Ch[:1500] *= np.float32(2.0) ** -12              # candidates of very different norms
+    key = np.unique(rng.integers(0, nq, 2000).astype(np.int64) * nc + rng.integers(0, nc, 2000))
+    mask = np.stack([key // nc, key % nc])
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    idx, val = ops.score_topk(D(Qh, dev), D(Ch, dev), k, rp, col, return_values=True)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy().astype(np.float64)
+    s64 = Qh.astype(np.float64) @ Ch.astype(np.float64).T
+    s64[mask[0], mask[1]] = -np.inf
+    for r in range(nq):
+        unit = max(np.abs(s64[r][np.isfinite(s64[r])]).max(), 1e-300)
+        order = np.lexsort((np.arange(nc), -s64[r]))[:k]
+        assert len(set(idx[r])) == k and not np.isin(idx[r], mask[1][mask[0] == r]).any()
+        if r == 20:
+            assert idx[r].tolist() == order.tolist() and np.all(val[r] == 0)
+            continue
+        np.testing.assert_allclose(val[r], s64[r][idx[r]], rtol=0, atol=2e-6 * unit)
+        assert np.all(np.diff(val[r]) <= 0)
+        for j in set(idx[r]) ^ set(order):          # only fp32-rounding near-ties at the k-th score may differ
+            assert abs(s64[r, j] - s64[r, order[-1]]) <= 2e-6 * unit, (r, j)
 
 
 def test_topk_knn_shape(ops, dev, golden):

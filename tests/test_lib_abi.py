@@ -78,13 +78,14 @@ def test_argument_errors_without_gpu(lib):
     # argument validation happens on the host before any launch
     assert lib.mmrec_spmm_csr_f32(None, None, None, None, None, None, None, None, 10, 32, 1.0, 0.0, 1.0,
                                   256, None, None, 0, 0, None, None) == 10002   # d != 64
-    assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 65, None, None, None, None) == 10001
+    assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 65, None, None, None, 0, None) == 10001
+    assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 5, None, None, None, 2, None) == 10001   # unknown flag
     assert lib.mmrec_linear_fwd_f32(None, None, None, None, 4, 6, 64, None, None) == 10002  # F % 4
 
 
 def test_topk_workspace_covers_both_kd64_paths(lib):
-    """kd = 64 calls may be served by the fp16 filter path or the materialised path (MMREC_TOPK_FILTER is read at
-    launch): the workspace query must cover both, grow with the problem, and stay far below the 4 nq nc bytes of a
+    """kd = 64 calls may be served by the fp16 filter path or the materialised path (the `flags` argument
+    decides at launch): the workspace query must cover both, grow with the problem, and stay far below the 4 nq nc bytes of a
     full score matrix at evaluation scale."""
     prev = 0
     for nq, nc in ((100, 1500), (4096, 7050), (19445, 7050), (39387, 23033)):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """score_topk (kd = 64, k = 50, 8 masked items per query) at the evaluation shapes of the BASELINE configs:
-fp16 filter + exact refinement vs the materialised fp32 path (MMREC_TOPK_FILTER=0), and agreement of the two.
+fp16 filter + exact refinement vs the materialised fp32 path (use_filter=False), and agreement of the two.
     python tools/prof_topk_shapes.py"""
 import os
 import sys
@@ -33,14 +33,13 @@ def main():
         rp, cl = rp.to(torch.int32), cols.to(torch.int32)
         res = {}
         for mode in ("1", "0"):
-            os.environ["MMREC_TOPK_FILTER"] = mode
             for _ in range(2):
-                out = hip_ops.score_topk(Q, C, 50, rp, cl, return_values=True)
+                out = hip_ops.score_topk(Q, C, 50, rp, cl, return_values=True, use_filter=mode == "1")
             torch.cuda.synchronize()
             reps = 3 if nc > 100000 else 10
             t0 = time.perf_counter()
             for _ in range(reps):
-                out = hip_ops.score_topk(Q, C, 50, rp, cl, return_values=True)
+                out = hip_ops.score_topk(Q, C, 50, rp, cl, return_values=True, use_filter=mode == "1")
             torch.cuda.synchronize()
             res[mode] = ((time.perf_counter() - t0) / reps * 1e3, out)
         same = (res["1"][1][0] == res["0"][1][0]).float().mean().item()
@@ -50,7 +49,6 @@ def main():
                                     nq / res["1"][0] / 1e3, res["0"][0], same, dv), flush=True)
         del Q, C, out, res
         torch.cuda.empty_cache()
-    os.environ.pop("MMREC_TOPK_FILTER", None)
 
 
 if __name__ == "__main__":
