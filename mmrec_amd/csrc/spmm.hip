@@ -17,7 +17,35 @@
 // the per-row summation order is fixed and independent of the row partition (multi-GPU == 1 GPU).
 #include "common.h"
 
+// tools/spmm_lab.py builds this file with a cache-policy mask (the library only ever uses MMREC_SPMM_POLICY below):
+// bit0 colidx / vals streamed with nontemporal loads, bit1 Y / acc written with nontemporal stores, bit2 X rows gathered
+// with nontemporal loads
+#ifndef MMREC_SPMM_LAB
+#define MMREC_SPMM_LAB 0
+#endif
+
 namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_x(const float4* p) {
+    if (MMREC_SPMM_LAB & 4) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ void st_y(float4* p, float4 y) {
+    if (MMREC_SPMM_LAB & 2) {
+        v4f v = {y.x, y.y, y.z, y.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+    } else {
+        *p = y;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    return (MMREC_SPMM_LAB & 1) ? __builtin_nontemporal_load(p) : *p;
+}
 
 // Embedding rows are d = 64 * DCH floats (DCH = 1 for every d = 64 graph model; 4 and 6 for MMGCN's
 // 256- and 384-wide modality layers): a 16-lane group walks a row in DCH chunks of 16 x float4.
@@ -36,10 +64,10 @@ __device__ __forceinline__ void store_row(const RowEpilogue& ep, int row, int la
         const size_t off = (size_t)row * (16 * DCH) + ch * 16 + lane16;  // float4 index
         float4 y = f4_scale(ep.alpha, sum[ch]);
         if (ep.Z) y = f4_fma(ep.beta, reinterpret_cast<const float4*>(ep.Z)[off], y);
-        if (ep.Y) reinterpret_cast<float4*>(ep.Y)[off] = y;
+        if (ep.Y) st_y(reinterpret_cast<float4*>(ep.Y) + off, y);
         if (ep.acc_out) {
             const float4 a = reinterpret_cast<const float4*>(ep.acc_in)[off];
-            reinterpret_cast<float4*>(ep.acc_out)[off] = f4_scale(ep.acc_scale, f4_add(a, y));
+            st_y(reinterpret_cast<float4*>(ep.acc_out) + off, f4_scale(ep.acc_scale, f4_add(a, y)));
         }
     }
 }
@@ -57,8 +85,8 @@ __device__ __forceinline__ void gather_span(const int32_t* __restrict__ colidx,
         int c = 0;
         float v = 0.f;
         if (k < e) {
-            c = colidx[k];
-            v = vals[k];
+            c = ld_stream(colidx + k);
+            v = ld_stream(vals + k);
         }
         const int cnt = min(16, e - base);
         // up to 8 gathers in flight per group per step (latency hiding for long-ish rows on small,
@@ -73,7 +101,7 @@ __device__ __forceinline__ void gather_span(const int32_t* __restrict__ colidx,
                 vv[u] = __shfl(v, j, 16);
 #pragma unroll
                 for (int ch = 0; ch < DCH; ++ch)
-                    x[u][ch] = (j < cnt) ? X4[(size_t)cj * (16 * DCH) + ch * 16 + lane16] : f4_zero();
+                    x[u][ch] = (j < cnt) ? ld_x(X4 + (size_t)cj * (16 * DCH) + ch * 16 + lane16) : f4_zero();
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u)

@@ -1,0 +1,356 @@
+"""GPU: device parity at the SHAPES of BASELINE.json configs 3, 4 and 5 (round-1 review, item 1).
+
+The golden files pin the kernels at a 200 x 90 dataset; the kernels, however, pick different code paths by size: the
+4096 -> 64 projection switches to the LDS-DMA `NT` forward and other split-K plans above 12,288 rows (gemm.hip), the
+fp16 top-K filter plans its candidate ranges from the candidate count (topk_filter.hip: filter_plan), the materialised
+kNN path tiles by both operand sizes.  Everything here runs those paths at Amazon-Sports (35,598 x 18,357), Amazon-Clothing
+(39,387 x 23,033) and C5 (500K items) sizes on synthetic data of that shape (mmrec_amd/synth.py: the datasets themselves
+are not shipped with the reference) and compares with the CPU oracle on the same inputs -- whole results where the oracle
+finishes in seconds, sampled rows in float64 where it would not (500K x 4096 features, 20,000 x 500,000 scores).
+
+Model steps go through the plugin API end to end (Config -> RecDataset -> loaders -> FREEDOM / BM3) with the device RNG draws
+injected (kept edges, dropout masks), reference call sites: freedom.py:189-210, bm3.py:97-147, trainer.py:302-310.
+tests/test_config_shapes_cpu.py runs the two model-step bodies on a miniature shape with the torch-CPU stand-in ops (host logic
+of these tests, checked without a GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmrec_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+USE_GPU = True
+
+
+def _dev():
+    return torch.device("cuda:0") if USE_GPU else torch.device("cpu")
+
+
+def rel_fro(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def close_scaled(a, b, rtol=1e-4, frac=1e-5, what=""):
+    """fp32 parity at size: |a - b| <= rtol |b| + frac max|b| (sums of thousands of fp32 products in another order
+    differ by a few ulps of the LARGEST partial sums, i.e. relative to the tensor's scale, not to each element) AND
+    relative Frobenius error <= 1e-5."""
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=frac * max(float(np.abs(b).max()), 1e-30), err_msg=what)
+    assert rel_fro(a, b) <= 1e-5, (what, rel_fro(a, b))
+
+
+def build_shape(root, model_name, ds, hyper):
+    """A `ds`-shaped synthetic dataset on disk in the reference's format, then the reference's own construction order
+    (quick_start.py:28-74) with OUR plumbing."""
+    from mmrec_amd import synth
+    from mmrec_amd.utils.configurator import Config
+    from mmrec_amd.utils.dataloader import EvalDataLoader, TrainDataLoader
+    from mmrec_amd.utils.dataset import RecDataset
+    from mmrec_amd.utils.utils import eval_batch_size, get_model, init_seed
+    synth.write_dataset(str(root), ds, seed=0)
+    cd = dict(hyper, gpu_id=0, use_gpu=USE_GPU, data_path=str(root) + "/", epochs=1, save_recommended_topk=False)
+    config = Config(model_name, ds, cd)
+    for k, v in cd.items():
+        config[k] = v
+    config["seed"] = 999
+    data = RecDataset(config)
+    str(data)                                    # as quick_start logs it (the summary fills inter_num & co.)
+    tr, va, te = data.split()
+    str(tr), str(va), str(te)
+    train_data = TrainDataLoader(config, tr, batch_size=config["train_batch_size"], shuffle=True)
+    valid_data = EvalDataLoader(config, va, additional_dataset=tr, batch_size=eval_batch_size(config))
+    init_seed(999)
+    train_data.pretrain_setup()
+    model = get_model(model_name)(config, train_data).to(config["device"])
+    assert config["device"].type == ("cuda" if USE_GPU else "cpu")
+    return config, train_data, valid_data, model
+
+
+def cpu_leaves(model):
+    return {n: p.detach().cpu().clone().requires_grad_() for n, p in model.named_parameters()}
+
+
+def check_grads(model, ref, names, tag, cancelling=()):
+    """`cancelling`: gradients that are analytically ZERO (FREEDOM's projection biases cancel in <u, p> - <u, n>): both
+    sides hold rounding noise of the summed terms only -- bounded against the scale of those terms instead."""
+    params = dict(model.named_parameters())
+    for n in names:
+        assert params[n].grad is not None, (tag, n)
+        if n in cancelling:
+            for g in (params[n].grad, ref[n].grad):
+                assert float(g.abs().max()) <= 1e-6 * cancelling[n], (tag, n, float(g.abs().max()))
+            continue
+        close_scaled(params[n].grad, ref[n].grad, what="%s d%s" % (tag, n))
+
+
+def local_mask(mask_rows, mask_cols, rows):
+    """the [2, n] mask restricted to the (ascending) sampled `rows`, row ids relative to the sample"""
+    pos = np.searchsorted(rows, mask_rows)
+    hit = (pos < rows.shape[0]) & (rows[np.minimum(pos, rows.shape[0] - 1)] == mask_rows)
+    return np.stack([pos[hit], np.asarray(mask_cols)[hit]])
+
+
+def topk_rows_match(idx, scores, mask, k, rows, val=None):
+    """Device top-k `idx[r]` of the sampled rows r = rows[j] against the oracle's trainer step on the CPU scores
+    `scores[j]` (orc.mask_topk, trainer.py:304-309; `mask` is relative to the sample): same ids up to near-ties at the
+    k-th score (another fp32 summation order), no duplicate, no masked id; optional device values `val`."""
+    ref_v, ref_i = orc.mask_topk(scores, mask, k)
+    s = scores.clone()
+    s[torch.as_tensor(mask[0]), torch.as_tensor(mask[1])] = -1e10
+    for j, r in enumerate(rows):
+        got = idx[r]
+        assert len(set(got.tolist())) == k
+        unit = max(float(s[j][s[j] > -1e9].abs().max()), 1e-30)
+        assert float(s[j][got].min()) > -1e9, ("masked id in the top-k", r)
+        for c in set(got.tolist()) ^ set(ref_i[j].tolist()):
+            assert abs(float(s[j][c]) - float(ref_v[j][-1])) <= 2e-6 * unit, (r, c)
+        np.testing.assert_allclose(np.sort(s[j][got].numpy())[::-1], ref_v[j].numpy(), rtol=0, atol=2e-6 * unit)
+        if val is not None:
+            np.testing.assert_allclose(val[r], ref_v[j].numpy(), rtol=0, atol=2e-6 * unit)
+
+
+# ------------------------------------------------------------------------------------------------ C3: FREEDOM / Sports
+def test_freedom_step_at_sports_shape(tmp_path):
+    """One FREEDOM training step at Amazon-Sports shape (BASELINE config 3: n_ui 2, n_mm 1, k 10, dropout 0.8) through the
+    plugin: pruned-graph propagation, item-item SpMM, both projections (image: 18,357 x 4096 -> the NT LDS-DMA forward and
+    the large-n split plans of dW; the gathered-rows form too), three BPR terms -- loss and ALL gradients vs the oracle
+    (freedom.py:189-210) with the multinomial draw injected; then the full-sort evaluation of all valid users against
+    18,357 candidates with the loader's real mask (trainer.py:302-310) on sampled + heaviest users."""
+    dev = _dev()
+    config, train_data, valid_data, model = build_shape(tmp_path, "FREEDOM", "sports",
+                                                        {"dropout": 0.8, "reg_weight": 1e-3, "lazy_feature_adam": False})
+    nu, ni = model.n_users, model.n_items
+    n = nu + ni
+    keep_len = int(model.edge_values.numel() * (1.0 - 0.8))
+    keep = torch.multinomial(model.edge_values.detach().cpu(), keep_len, generator=torch.Generator().manual_seed(1))
+    model.set_kept_edges(keep.to(dev))
+    batch = next(iter(train_data))
+    assert batch.shape[0] == 3 and batch.shape[1] == config["train_batch_size"]
+    b = batch.cpu().numpy()
+    # oracle
+    ref = cpu_leaves(model)
+    a_idx, a_val = orc.masked_adj_coo(model.edge_indices.cpu().numpy(), keep.numpy(), nu, ni)
+    adj = orc.sparse_coo(a_idx, a_val, n)
+    m_idx, m_val = model.mm_adj.to_coo_host()
+    mm = orc.sparse_coo(m_idx, m_val, ni, ni)
+    args = (ref["user_embedding.weight"], ref["item_id_embedding.weight"], ref["image_embedding.weight"],
+            ref["image_trs.weight"], ref["image_trs.bias"], ref["text_embedding.weight"], ref["text_trs.weight"],
+            ref["text_trs.bias"])
+    loss_ref = orc.freedom_loss(adj, mm, *args, config["n_ui_layers"], config["n_mm_layers"], b, 1e-3)
+    loss_ref.backward()
+    with torch.no_grad():
+        u_ref, i_ref = orc.freedom_forward(adj, mm, args[0], args[1], config["n_ui_layers"], config["n_mm_layers"])
+    ua, ia = model.forward(model.masked_adj)
+    close_scaled(ua, u_ref, what="user embeddings"), close_scaled(ia, i_ref, what="item embeddings")
+    names = list(ref)
+    for lazy in (False, True):       # all-items projection (reference form), then the plugin's default gathered rows
+        model.zero_grad()
+        model.lazy_projection = lazy
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(loss_ref.detach()), rtol=1e-5)
+        # d bias = sum_b coef_b (1 - 1): the terms that cancel are O(reg_weight / B) each
+        check_grads(model, ref, names, "FREEDOM/sports lazy=%s" % lazy,
+                    cancelling={"image_trs.bias": 1e-3, "text_trs.bias": 1e-3})
+    # full-sort evaluation at 35,598 x 18,357 through the plugin, real mask
+    model.eval()
+    full = orc.sparse_coo(*model.norm_adj.to_coo_host(), n)
+    with torch.no_grad():
+        u_ref, i_ref = orc.freedom_forward(full, mm, args[0].detach(), args[1].detach(), config["n_ui_layers"],
+                                           config["n_mm_layers"])
+    batches = list(valid_data)
+    assert len(batches) == 1 or not USE_GPU          # fused evaluation: all users of the split in one call
+    users, mask = batches[0][0], batches[0][1]
+    idx = model.full_sort_topk(batches[0], 50).cpu().numpy()
+    mrows, mcols = mask[0].cpu().numpy(), mask[1].cpu().numpy()
+    cnt = np.bincount(mrows, minlength=users.shape[0])
+    rng = np.random.default_rng(0)
+    rows = np.unique(np.concatenate([np.argsort(-cnt)[:64], rng.choice(users.shape[0], min(2048, users.shape[0]), False)]))
+    s = orc.full_sort_scores(u_ref, i_ref, users.cpu()[rows])
+    topk_rows_match(idx, s, local_mask(mrows, mcols, rows), 50, rows)
+
+
+# ------------------------------------------------------------------------------------------------ C4: BM3 / Clothing
+def test_bm3_step_at_clothing_shape(tmp_path, monkeypatch):
+    """One BM3 training step at Amazon-Clothing shape (BASELINE config 4: n_layers 2, dropout 0.3) with the four
+    F.dropout keep-masks injected: loss and all gradients vs the oracle (bm3.py:97-147), in the reference's all-items
+    form and in the plugin's default gathered-rows form; then the full-sort evaluation (predictor on all rows + 39,387 x
+    23,033 top-50) against the oracle on sampled users."""
+    dev = _dev()
+    config, train_data, valid_data, model = build_shape(tmp_path, "BM3", "clothing",
+                                                        {"n_layers": 2, "dropout": 0.3, "reg_weight": 0.1,
+                                                         "lazy_feature_adam": False})
+    nu, ni = model.n_users, model.n_items
+    n = nu + ni
+    batch = next(iter(train_data))
+    assert batch.shape[0] == 2
+    gen = torch.Generator().manual_seed(5)
+    masks_cpu = [(torch.rand(r, 64, generator=gen) >= 0.3).float() for r in (nu, ni, ni, ni)]
+    ref = cpu_leaves(model)
+    adj = orc.sparse_coo(*model.norm_adj.to_coo_host(), n)
+    loss_ref = orc.bm3_loss(adj, ref["user_embedding.weight"], ref["item_id_embedding.weight"], ref["predictor.weight"],
+                            ref["predictor.bias"], ref["image_embedding.weight"], ref["image_trs.weight"],
+                            ref["image_trs.bias"], ref["text_embedding.weight"], ref["text_trs.weight"],
+                            ref["text_trs.bias"], 2, batch.cpu().numpy(), 0.1, config["cl_weight"], 0.3,
+                            [m.numpy() for m in masks_cpu])
+    loss_ref.backward()
+    import mmrec_amd.models.bm3 as bm3mod
+    real_dropout = bm3mod.F.dropout
+    for lazy in (False, True):
+        model.zero_grad()
+        model.lazy_projection = lazy
+        masks = [m.to(dev) for m in masks_cpu]
+
+        def replay(x, p=0.5, training=True, inplace=False):
+            return x * masks.pop(0) / (1.0 - p)
+        monkeypatch.setattr(bm3mod.F, "dropout", replay)
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(loss_ref.detach()), rtol=1e-5)
+        check_grads(model, ref, list(ref), "BM3/clothing lazy=%s" % lazy)
+    monkeypatch.setattr(bm3mod.F, "dropout", real_dropout)
+    model.eval()
+    with torch.no_grad():
+        u0, i0 = orc.bm3_forward(adj, ref["user_embedding.weight"].detach(), ref["item_id_embedding.weight"].detach(), 2)
+        u_ref = orc.linear(u0, ref["predictor.weight"].detach(), ref["predictor.bias"].detach())
+        i_ref = orc.linear(i0, ref["predictor.weight"].detach(), ref["predictor.bias"].detach())
+    batches = list(valid_data)
+    users, mask = batches[0][0], batches[0][1]
+    idx = model.full_sort_topk(batches[0], 50).cpu().numpy()
+    mrows, mcols = mask[0].cpu().numpy(), mask[1].cpu().numpy()
+    rng = np.random.default_rng(1)
+    rows = np.sort(rng.choice(users.shape[0], min(2048, users.shape[0]), False))
+    s = orc.full_sort_scores(u_ref, i_ref, users.cpu()[rows])
+    topk_rows_match(idx, s, local_mask(mrows, mcols, rows), 50, rows)
+
+
+# ------------------------------------------------------------------------------------------------ P3 at size
+@pytest.mark.parametrize("n,F", [(18357, 4096), (23033, 4096), (18357, 384), (23033, 384), (12289, 4096)])
+def test_linear_fwd_bwd_at_config_shapes(n, F):
+    """hip_ops.linear forward + dW + db + dX at the item counts of configs 3 / 4 (and just above the 12,288-row switch to
+    the NT LDS-DMA forward, gemm.hip) for both modalities, whole tensors vs the oracle (freedom.py:205,208; bm3.py:102-104).
+    Features as the synthetic datasets make them: image = relu(N(0,1)), text = row-normalised N(0,1)."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + F)
+    X = torch.randn(n, F, generator=g)
+    X = torch.relu(X) if F == 4096 else X / X.norm(dim=1, keepdim=True)
+    X.requires_grad_()
+    W = torch.empty(64, F)
+    torch.nn.init.xavier_normal_(W, generator=g)
+    W.requires_grad_()
+    b = (torch.randn(64, generator=g) * 0.01).requires_grad_()
+    G = torch.randn(n, 64, generator=g) * 1e-3        # upstream gradient of a BPR term: small, asymmetric
+    ref = orc.linear(X, W, b)
+    ref.backward(G)
+    Xd, Wd, bd = (t.detach().to(dev).requires_grad_() for t in (X, W, b))
+    Y = hip_ops.linear(Xd, Wd, bd)
+    Y.backward(G.to(dev))
+    close_scaled(Y, ref, what="Y")
+    close_scaled(Wd.grad, W.grad, what="dW")
+    close_scaled(bd.grad, b.grad, what="db")
+    close_scaled(Xd.grad, X.grad, what="dX")
+
+
+def test_linear_at_c5_item_count_sampled_rows():
+    """n = 500,000 x F = 4096 (config 5: 8.2 GB of features, generated on the device): Y and dX on sampled rows and dW / db
+    whole, all against float64 restatements computed from the same device data in slabs."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    n, F = (500_000, 4096) if USE_GPU else (3000, 4096)
+    g = torch.Generator(device=dev).manual_seed(11)
+    X = torch.relu(torch.randn(n, F, device=dev, generator=g)).requires_grad_()
+    W = (torch.randn(64, F, device=dev, generator=g) * (2.0 / (F + 64)) ** 0.5).requires_grad_()
+    b = (torch.randn(64, device=dev, generator=g) * 0.01).requires_grad_()
+    G = torch.randn(n, 64, device=dev, generator=g) * 1e-3
+    Y = hip_ops.linear(X, W, b)
+    Y.backward(G)
+    rows = torch.randperm(n, device=dev, generator=g)[:4096]
+    Xs, W64, G64 = X.detach()[rows].double().cpu(), W.detach().double().cpu(), G.double().cpu()
+    close_scaled(Y.detach()[rows], (Xs @ W64.t() + b.detach().double().cpu()).float(), what="Y rows")
+    close_scaled(X.grad[rows], (G64[rows.cpu()] @ W64).float(), what="dX rows")
+    dW = torch.zeros(64, F, dtype=torch.float64)
+    for r0 in range(0, n, 50_000):          # float64 accumulation over slabs of fp32 device products is NOT a reference;
+        xs = X.detach()[r0:r0 + 50_000].double().cpu()      # the slab itself is multiplied in float64 on the host
+        dW += G64[r0:r0 + 50_000].t() @ xs
+    close_scaled(W.grad, dW.float(), what="dW")
+    close_scaled(b.grad, G64.sum(0).float(), what="db")
+
+
+# ------------------------------------------------------------------------------------------------ P5 / P6 at size
+def _eval_case(shape, dev):
+    """LightGCN-propagated Xavier embeddings on the `shape`-shaped synthetic graph + the train edges as the mask: what a
+    full-sort evaluation of that dataset hands to score_topk (smoothed embeddings share a large common component)."""
+    from mmrec_amd import hip_ops, synth
+    nu, ni, eu, ei = synth.shaped_edges(shape, seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    g = hip_ops.CsrGraph.from_coo_host(np.stack([r, c]), v, nu + ni, nu + ni, dev, symmetric=True)
+    gen = torch.Generator().manual_seed(3)
+    E0 = torch.empty(nu + ni, 64)
+    torch.nn.init.xavier_uniform_(E0[:nu], generator=gen), torch.nn.init.xavier_uniform_(E0[nu:], generator=gen)
+    E = hip_ops.lightgcn_mean(g, E0.to(dev), 2)
+    return nu, ni, eu, ei, E[:nu].contiguous(), E[nu:].contiguous()
+
+
+@pytest.mark.parametrize("shape", ["sports", "clothing"])
+def test_score_topk_at_eval_shapes(shape):
+    """mmrec_score_topk_f32 at 35,598 x 18,357 and 39,387 x 23,033 (other range / stage plans of the fp16 filter than
+    the Baby shape), k = 50, the dataset's train positives masked (trainer.py:304-309): every query is served on the
+    device, 4096 sampled + the 64 most-masked queries are checked against orc.mask_topk."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    nu, ni, eu, ei, U, I = _eval_case(shape, dev)
+    rp, col = hip_ops.mask_to_csr(np.stack([eu, ei]), nu, dev)
+    idx, val = hip_ops.score_topk(U, I, 50, rp, col, return_values=True)
+    idx, val = idx.cpu().numpy(), val.cpu()
+    assert np.all(np.diff(val.numpy(), axis=1) <= 0)
+    cnt = np.bincount(eu, minlength=nu)
+    rng = np.random.default_rng(0)
+    rows = np.unique(np.concatenate([np.argsort(-cnt)[:64], rng.choice(nu, 4096, False)]))
+    Uc, Ic = U.cpu(), I.cpu()
+    scores = orc.full_sort_scores(Uc, Ic, rows)
+    topk_rows_match(idx, scores, local_mask(eu, ei, rows), 50, rows, val=val.numpy())
+
+
+def test_score_topk_c5_block_vs_oracle():
+    """A 20,000-user block against all 500,000 items (config 5; the [20,000, 500,000] score block would be 40 GB and is
+    never formed), 16 masked items per user, k = 50: 512 sampled users vs orc.mask_topk on the CPU."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    nq, nc, k = (20_000, 500_000, 50) if USE_GPU else (300, 9000, 50)
+    gen = torch.Generator().manual_seed(9)
+    common = torch.randn(64, generator=gen) * 0.05
+    Q = torch.randn(nq, 64, generator=gen) * 0.03 + common
+    C = torch.randn(nc, 64, generator=gen) * 0.03 + common
+    mrow = np.repeat(np.arange(nq), 16)
+    mcol = np.random.default_rng(2).integers(0, nc, nq * 16)
+    key = np.unique(mrow.astype(np.int64) * nc + mcol)
+    mask = np.stack([key // nc, key % nc])
+    rp, col = hip_ops.mask_to_csr(mask, nq, dev)
+    idx = hip_ops.score_topk(Q.to(dev), C.to(dev), k, rp, col).cpu().numpy()
+    rows = np.sort(np.random.default_rng(3).choice(nq, min(512, nq), False))
+    scores = orc.full_sort_scores(Q, C, rows)
+    topk_rows_match(idx, scores, local_mask(mask[0], mask[1], rows), k, rows)
+
+
+@pytest.mark.parametrize("F", [384, 4096])
+def test_knn_graph_at_sports_item_count(F):
+    """P6 at 18,357 items (config 3's frozen item-item graph, freedom.py:79-82): kNN(10) over row-normalised features on the
+    materialised general-K GEMM path; 1024 sampled query rows vs the CPU (self first, same neighbour sets up to near-ties)."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    n = 18357 if USE_GPU else 700
+    g = torch.Generator().manual_seed(F)
+    X = torch.randn(n, F, generator=g)
+    X = torch.relu(X) if F == 4096 else X
+    Xn = X / X.norm(dim=1, keepdim=True)
+    idx = hip_ops.score_topk(Xn.to(dev), Xn.to(dev), 10).cpu().numpy()
+    assert np.all(idx[:, 0] == np.arange(n))
+    rows = np.sort(np.random.default_rng(F).choice(n, min(1024, n), False))
+    s = (Xn[rows].double() @ Xn.double().t()).float()
+    topk_rows_match(idx, s, np.zeros((2, 0), dtype=np.int64), 10, rows)
