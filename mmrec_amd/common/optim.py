@@ -58,6 +58,18 @@ class HipAdam(torch.optim.Optimizer):
             if id(group) in self._dev:
                 self._dev[id(group)][1].fill_(float(group['lr']))
 
+    def state_dict(self):
+        """Under hipGraph replay the host mirror of `step` advances once per CAPTURE, the device counter once per
+        replay: the device counter is the truth (a resumed run computes its bias corrections from the saved count)."""
+        if self.capturable:
+            for group in self.param_groups:
+                if id(group) in self._dev:
+                    n = int(self._dev[id(group)][0].item())
+                    for p in group['params']:
+                        if p in self.state and self.state[p] and getattr(p, '_lazy_table', None) is None:
+                            self.state[p]['step'] = n
+        return super().state_dict()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

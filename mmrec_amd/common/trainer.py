@@ -33,6 +33,8 @@ class AbstractTrainer(object):
 
 
 class Trainer(AbstractTrainer):
+    NAN_CHECK_EVERY = 64
+
     def __init__(self, config, model, mg=False):
         super().__init__(config, model)
         self.logger = getLogger()
@@ -96,12 +98,12 @@ class Trainer(AbstractTrainer):
         calls `loss.item()` + `isnan` after every batch (a device sync each), here the per-batch loss
         scalars stay on the device and are read once per epoch, so host-side batch assembly /
         negative sampling overlaps the GPU step.  Values, their float64 sum and the NaN abort are the
-        same (the abort is noticed at the end of the epoch instead of mid-epoch)."""
+        same (the abort is noticed within NAN_CHECK_EVERY batches instead of at the batch itself)."""
         if not self.req_training:
             return 0.0, []
         self.model.train()
         loss_func = loss_func or self.model.calculate_loss
-        per_batch, tuple_parts = [], None
+        per_batch, tuple_parts, nan_probe = [], None, []
         graphed = self._graphed_step(loss_func)
         if graphed is not None:
             graphed.invalidate()        # pre_epoch_processing may have rebuilt the model's graphs
@@ -128,9 +130,20 @@ class Trainer(AbstractTrainer):
                 clip_grad_norm_(self.model.parameters(), **self.clip_grad_norm)
             self.optimizer.step()
             per_batch.append(loss.detach().reshape(()))      # one element, any shape (EmbLoss makes [1]), like .item()
+            if self.mg and batch_idx % self.beta == 0:
+                nan_probe.append(loss2.detach().reshape(()))  # the reference checks the mirrored loss too (:176)
+            # the reference returns at the first NaN batch (:160-163); here a NaN is noticed within NAN_CHECK_EVERY
+            # batches (one small device read), before a whole epoch of NaN updates is spent
+            if (batch_idx + 1) % self.NAN_CHECK_EVERY == 0:
+                if bool(torch.isnan(torch.stack(per_batch[-self.NAN_CHECK_EVERY:] + nan_probe)).any()):
+                    break                                     # which batch: decided below from all the values
         if not per_batch:
             return 0.0, []
-        values = torch.stack(per_batch).cpu().tolist()        # the one sync of the epoch
+        values = torch.stack(per_batch + nan_probe).cpu().tolist()        # the one sync of a healthy epoch
+        mirrored, values = values[len(per_batch):], values[:len(per_batch)]
+        if all(v == v for v in values) and any(v != v for v in mirrored):
+            self.logger.info('Loss is nan at epoch: {} (mirrored loss). Exiting.'.format(epoch_idx))
+            return per_batch[-1], torch.tensor(0.0)
         for batch_idx, v in enumerate(values):
             if v != v:
                 self.logger.info('Loss is nan at epoch: {}, batch index: {}. Exiting.'.format(epoch_idx, batch_idx))
@@ -202,20 +215,49 @@ class Trainer(AbstractTrainer):
         flush_lazy_tables(self.model)      # row-lazy tables: apply what is still postponed (no-op otherwise)
         return self.best_valid_score, self.best_valid_result, self.best_test_upon_valid
 
+    def _dense_topk(self, batch, k):
+        """The reference's evaluation step (trainer.py:302-310): full_sort_predict -> scores[mask] = -1e10 -> topk.
+        The fused evaluation makes the loaders hand over up to `hip_eval_batch_size` users at once; a model that takes
+        THIS path (no `full_sort_topk`, k above the fused kernel's limit, an embedding width it does not serve) would
+        then materialise a [65536, n_items] score block, so the batch is walked in the reference's `eval_batch_size`
+        slices (per-user results do not depend on the batching)."""
+        users, mask = batch[0], batch[1]
+        step = max(int(self.test_batch_size or 4096), 1)
+        if users.shape[0] <= step:
+            scores = self.model.full_sort_predict(batch)
+            scores[mask[0], mask[1]] = -1e10
+            return torch.topk(scores, k, dim=-1)[1]
+        out = []
+        for a in range(0, users.shape[0], step):
+            b = min(a + step, users.shape[0])
+            sel = (mask[0] >= a) & (mask[0] < b)
+            sub = torch.stack((mask[0][sel] - a, mask[1][sel]))
+            scores = self.model.full_sort_predict([users[a:b], sub])
+            scores[sub[0], sub[1]] = -1e10
+            out.append(torch.topk(scores, k, dim=-1)[1])
+        return torch.cat(out, dim=0)
+
     @torch.no_grad()
     def evaluate(self, eval_data, is_test=False, idx=0):
         self.model.eval()
         k = max(self.config['topk'])
         fused = self.fused_eval and hasattr(self.model, 'full_sort_topk')
+        if fused:
+            from mmrec_amd import hip_ops
+            fused = k <= hip_ops.TOPK_MAX        # torch.topk takes any k (e.g. topk: [10, 20, 50, 100]); the kernel 64
         topk_batches = []
         for batch in eval_data:
             if fused:
-                topk_batches.append(self.model.full_sort_topk(batch, k))
-                continue
-            scores = self.model.full_sort_predict(batch)
-            mask = batch[1]
-            scores[mask[0], mask[1]] = -1e10
-            topk_batches.append(torch.topk(scores, k, dim=-1)[1])
+                try:
+                    topk_batches.append(self.model.full_sort_topk(batch, k))
+                    continue
+                except Exception as ex:          # a shape the fused kernel does not serve: the reference's path
+                    from mmrec_amd._lib import MMRecHipError
+                    if not isinstance(ex, MMRecHipError):
+                        raise
+                    self.logger.warning('fused top-K evaluation unavailable for this model (%s); using the dense path' % ex)
+                    fused = False
+            topk_batches.append(self._dense_topk(batch, k))
         if self.device_metrics and topk_batches and topk_batches[0].is_cuda:
             return self.evaluator.evaluate_device(topk_batches, eval_data, is_test=is_test, idx=idx)
         return self.evaluator.evaluate(topk_batches, eval_data, is_test=is_test, idx=idx)

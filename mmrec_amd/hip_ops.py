@@ -181,7 +181,7 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, Z, g):
-        ctx.g, ctx.has_z = g, Z is not None
+        ctx.g, ctx.has_z, ctx.x_rows = g, Z is not None, X.shape[0]
         X = X.contiguous()
         Y = torch.empty(g.n_rows, X.shape[1], dtype=torch.float32, device=X.device)
         spmm_raw(g, X, Y=Y, Z=None if Z is None else Z.contiguous(), beta=1.0)
@@ -193,7 +193,9 @@ class _SpMM(torch.autograd.Function):
         gt = ctx.g.transpose()
         dX = None
         if ctx.needs_input_grad[0]:
-            dX = torch.empty(gt.n_rows, dY.shape[1], dtype=torch.float32, device=dY.device)
+            # X may carry more rows than the graph has columns (spmm_raw allows it): they receive no gradient
+            alloc = torch.empty if ctx.x_rows == gt.n_rows else torch.zeros
+            dX = alloc(ctx.x_rows, dY.shape[1], dtype=torch.float32, device=dY.device)
             spmm_raw(gt, dY, Y=dX)
         return dX, (dY if ctx.has_z and ctx.needs_input_grad[1] else None), None
 

@@ -152,3 +152,27 @@ def test_reference_model_files_run_on_our_plumbing(tmp_path_factory, golden, run
     res, err = _batch_results("files", tmp_path_factory, golden)
     assert run in res, err
     _check_against_trajectory(res[run], run)
+
+
+def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
+    """Round-1 advice: (1) a model on the reference's dense evaluation path (no `full_sort_topk`, or k above the fused
+    kernel's limit) must not be handed the fused path's 65,536-user batches as ONE [batch, n_items] score block: the
+    Trainer walks such a batch in `eval_batch_size` slices, with the same per-user results; (2) `topk: [5, 70]` (k > 64,
+    fine for torch.topk in the reference) evaluates through the dense path instead of raising after a training epoch."""
+    from mmrec_amd.common.trainer import Trainer
+    config, train_data, valid_data, model = G.build(tmp_path, golden, "LightGCN", {"n_layers": 2, "reg_weight": 1e-4})
+    trainer = Trainer(config, model)
+    fused = trainer.evaluate(valid_data)
+    trainer.fused_eval = False
+    whole = trainer.evaluate(valid_data)
+    sizes = []
+    real = model.full_sort_predict
+    model.full_sort_predict = lambda batch: (sizes.append(int(batch[0].shape[0])), real(batch))[1]
+    trainer.test_batch_size = 37
+    sliced = trainer.evaluate(valid_data)
+    assert sliced == whole == fused and max(sizes) <= 37 and len(sizes) > 1
+    config["topk"] = [5, 70]
+    t2 = Trainer(config, model)                    # fused evaluation on, but k = 70 > TOPK_MAX = 64
+    sizes.clear()
+    res = t2.evaluate(valid_data)
+    assert sizes and res["recall@5"] == whole["recall@5"] and "recall@70" in res
