@@ -10,21 +10,30 @@ propagation E <- A E (d = 64, fp32) on the synthetic 10M-edge graph of BASELINE.
 (1M users x 500K items, nnz = 20M directed, N = 1.5M), the configuration BASELINE.md section 3 says
 the HBM roofline is graded on (Amazon-Baby is cache resident; its numbers ride along in `extra`).
 value = directed nnz x layers x steps / wall time (max over ranks), whole job.
-At N > 1 the rows are sharded (users and items blockwise) and the blocks are all-gathered over
-RCCL/xGMI after every layer: the total work is fixed -> "scaling": "strong".
+At N > 1 the rows are sharded (users and items blockwise, nnz-balanced) and the blocks are all-gathered over
+RCCL/xGMI after every layer, chunk by chunk under the next chunk's SpMM: the total work is fixed -> "scaling": "strong".
 
-roofline: HIP events on the launch stream bracket every SpMM call inside the timed region;
-achieved = algorithmic bytes (264 B/nnz + 260 B/row) / mean call duration.
+roofline: HIP events on the launch stream bracket every SpMM call inside the timed region.  The headline
+`achieved` / `frac` are the COUNTER view: bytes the launch moves past L2 (rocprofv3 FETCH_SIZE, x2 on gfx950 for
+16-B/lane reads, + WRITE_SIZE; collected in-run by re-running a few launches of the same graph under rocprofv3, one
+--pmc pass per counter set) / mean launch duration / 8 TB/s -- <= 1 by construction.  The gather-model figure of
+SURVEY.md 8d (264 B/nnz + 260 B/row: every nonzero fetches its X row; > 1 of peak because L2 absorbs hot rows), the
+compulsory bound (8 B/nnz + 516 B/row) and the L2 hit rate ride next to it.
 cpu_baseline (rank 0, N = 1): the reference's own operator, torch.sparse.mm on the uncoalesced COO
 adjacency (freedom.py:172), on a bounded sample (a few layers) with all host cores.
 """
 from __future__ import annotations
 
 import argparse
-import json
+import csv
 import ctypes
+import glob
+import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -46,21 +55,26 @@ def alg_bytes(nnz, n_rows):
     return 264 * nnz + 260 * n_rows
 
 
-def build_c5(dev, rank, world, layout, multi):
+def alg_compulsory_bytes(nnz, n_rows):
+    return 8 * nnz + 516 * n_rows          # colidx + vals once, rowptr + one read of X and one write of Y per row
+
+
+def build_c5(dev, rank, world, layout, multi, n_chunks=None):
     from mmrec_amd import hip_ops, synth
     from mmrec_amd.dist import BipartiteSharding
     t = time.time()
     nu, ni, eu, ei = synth.shaped_edges("c5", seed=0)
     r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
     log("c5 graph generated on host in %.1fs (nnz %d)" % (time.time() - t, r.shape[0]))
-    sh = BipartiteSharding(nu, ni, world)
     if not multi:
+        sh = BipartiteSharding(nu, ni, world)
         g = hip_ops.CsrGraph.from_coo_device(
             torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
             torch.from_numpy(v).to(dev), nu + ni, nu + ni, symmetric=True)
         return sh, g, None, None, r, c, v
     if layout == "allreduce":
         # users sharded, items replicated: rank r keeps R_r (its users' rows) and R_r^T
+        sh = BipartiteSharding(nu, ni, world)
         ne = eu.shape[0]
         ub = -(-nu // world)
         u0, u1 = rank * ub, min((rank + 1) * ub, nu)
@@ -72,15 +86,19 @@ def build_c5(dev, rank, world, layout, multi):
         r_blk = hip_ops.CsrGraph.from_coo_device(lu, li, wv, u1 - u0, ni)
         rt_blk = hip_ops.CsrGraph.from_coo_device(li, lu, wv, ni, u1 - u0)
         return sh, None, r_blk, rt_blk, r, c, v
-    rp, cp = sh.padded_coo(r, c)
-    blocks = []
-    for lo, hi in (sh.user_rows(rank), sh.item_rows(rank)):
-        s, e = np.searchsorted(rp, lo, "left"), np.searchsorted(rp, hi, "left")   # rows are ascending
-        blocks.append(hip_ops.CsrGraph.from_coo_device(
-            torch.from_numpy((rp[s:e] - lo).astype(np.int32)).to(dev),
-            torch.from_numpy(cp[s:e].astype(np.int32)).to(dev), torch.from_numpy(v[s:e]).to(dev),
-            hi - lo, sh.N_pad))
-    return sh, None, blocks[0], blocks[1], r, c, v
+    # rows sharded, nnz-balanced cut points, `n_chunks` row chunks per rank (chunk-major padded id space)
+    if n_chunks is None:      # a chunk should stay a >= ~1M-nnz SpMM (tens of us), else launches dominate
+        n_chunks = int(min(4, max(1, r.shape[0] // max(world, 1) // 1_000_000)))
+    sh = BipartiteSharding.from_coo(r, nu, ni, world, n_chunks=n_chunks)
+
+    def make(lr, pc, vals, n_rows, n_cols):
+        if isinstance(dev, str) or dev.type != "cuda":       # the CPU stand-in of the block-construction test
+            return hip_ops.CsrGraph.from_coo_host(np.stack([lr, pc]), vals, n_rows, n_cols, dev)
+        return hip_ops.CsrGraph.from_coo_device(torch.from_numpy(lr.astype(np.int32)).to(dev),
+                                                torch.from_numpy(pc.astype(np.int32)).to(dev),
+                                                torch.from_numpy(np.ascontiguousarray(vals)).to(dev), n_rows, n_cols)
+    ublocks, iblocks = sh.rank_blocks(r, c, v, rank, make)
+    return sh, None, ublocks, iblocks, r, c, v
 
 
 def cpu_baseline(r, c, v, n, max_seconds=25.0):
@@ -346,6 +364,84 @@ def extra_baby(dev):
     return out
 
 
+def pmc_child(path):
+    """rocprofv3 child: a few launches of mmrec_spmm_csr_f32 on the graph the parent saved, nothing else."""
+    from mmrec_amd import hip_ops
+    dev = torch.device("cuda", 0)
+    z = np.load(path)
+    n = int(z["n"])
+    g = hip_ops.CsrGraph(torch.from_numpy(z["rowptr"]).to(dev), torch.from_numpy(z["colidx"]).to(dev),
+                         torch.from_numpy(z["vals"]).to(dev), n, n, symmetric=True, rowptr_host=z["rowptr"])
+    x = torch.rand(n, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) - 0.5
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        hip_ops.spmm_raw(g, x, Y=y)
+        x, y = y, x
+    torch.cuda.synchronize()
+
+
+def measure_traffic(g, n_nodes):
+    """Counters of the dominant kernel, IN THIS RUN: the same graph is handed to a child process that is run under
+    `rocprofv3 --kernel-trace --pmc <set>` once per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass:
+    MI355X_MICROARCH.md, rocprofv3 PMC slots).  Returns per-launch numbers (rows/chunks kernel + long-row reduce) or
+    None when rocprofv3 is not usable here (the committed profile is quoted instead, and the line says so)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mmrec_pmc_", dir="/tmp")
+    try:
+        path = os.path.join(tmp, "graph.npz")
+        np.savez(path, rowptr=g.rowptr_host, colidx=g.colidx.cpu().numpy(), vals=g.vals.cpu().numpy(), n=n_nodes)
+        out = {}
+        env = dict(os.environ, TMPDIR="/tmp")
+        for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pm", "--",
+                                                                 sys.executable, os.path.abspath(__file__), "--pmc-child", path]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                log("rocprofv3 pass '%s' failed (rc %d): %s" % (tag, r.returncode, r.stderr[-300:]))
+                return None
+            per = {}
+            launches = 0
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"]
+                if "spmm_rows_kernel" in k or "spmm_long_reduce_kernel" in k:
+                    per[row["Counter_Name"]] = per.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    if "spmm_rows_kernel" in k and row["Counter_Name"] == counters[0]:
+                        launches += 1
+            if not launches:
+                return None
+            for c in counters:
+                out[c] = per.get(c, 0.0) / launches
+        fetch = out["FETCH_SIZE"] * 1024.0 * 2.0        # KB -> B; x2: gfx950 tallies 16-B/lane reads at half size
+        write = out["WRITE_SIZE"] * 1024.0
+        return {"fetch_bytes": fetch, "write_bytes": write, "bytes": fetch + write,
+                "l2_hit_rate": out["TCC_HIT_sum"] / max(out["TCC_HIT_sum"] + out["TCC_MISS_sum"], 1.0),
+                "source": "in-run: rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum}, one "
+                          "pass each, 4 launches of this graph; FETCH_SIZE x2 (gfx950 wide-read correction), per launch"}
+    except Exception as ex:   # the headline number must not be lost to the profiler
+        log("in-run PMC collection failed: %r" % (ex,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def committed_traffic():
+    pmc = os.path.join(ROOT, "profiles", "spmm_pmc.json")
+    try:
+        j = json.load(open(pmc))
+        sha = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles/spmm_pmc.json"],
+                             capture_output=True, text=True).stdout.strip() or "untracked"
+        return {"fetch_bytes": j["fetch_bytes_corrected_x2_gfx950"], "write_bytes": j["write_bytes"],
+                "bytes": j["hbm_bytes_per_launch"], "l2_hit_rate": j["l2_hit_rate"],
+                "source": "profiles/spmm_pmc.json@%s (a committed profile of the same launch, NOT measured in this run)" % sha}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,14 +449,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run launches under rocprofv3 for roofline.traffic")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: run the N > 1 code path (process group, sharded blocks, "
                          "collectives) with a single rank")
-    ap.add_argument("--layout", choices=["allreduce", "allgather"], default="allreduce",
-                    help="N > 1: 'allreduce' = users sharded / items replicated, item partial sums "
-                         "all-reduced per layer (smaller volume); 'allgather' = rows sharded, blocks "
-                         "all-gathered per layer (bit-exact vs 1 GPU)")
+    ap.add_argument("--layout", choices=["allgather", "allreduce"], default="allgather",
+                    help="N > 1: 'allgather' (default; north_star's wording) = rows sharded nnz-balanced, blocks "
+                         "all-gathered per layer in chunks under the next chunk's SpMM, bit-exact vs 1 GPU; "
+                         "'allreduce' = users sharded / items replicated, item partial sums all-reduced per "
+                         "layer (2/3 of the volume, fp32-rounding-equal)")
+    ap.add_argument("--chunks", type=int, default=None, help="row chunks per rank of the allgather layout (default: auto)")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args.pmc_child)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -387,7 +489,7 @@ def main():
 
     from mmrec_amd import hip_ops
     from mmrec_amd.dist import ShardedPropagator
-    sh, g, ublk, iblk, r, c, v = build_c5(dev, rank, world, args.layout, multi)
+    sh, g, ublk, iblk, r, c, v = build_c5(dev, rank, world, args.layout, multi, args.chunks)
     nnz_total, n_nodes = int(r.shape[0]), sh.n_users + sh.n_items
     gen = torch.Generator(device=dev).manual_seed(0)   # same seed -> same X0 on every rank
     X0 = torch.rand(sh.N_pad if multi else n_nodes, 64, device=dev, generator=gen) - 0.5
@@ -395,16 +497,17 @@ def main():
     ev = []   # (start, stop) HIP events around every SpMM call in the timed region
     timed = False
 
-    def local_spmm(block, X, Y):
+    def local_spmm(block, X, Y, **ep):
         if timed:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            hip_ops.spmm_raw(block, X, Y=Y)
+            hip_ops.spmm_raw(block, X, Y=Y, **ep)
             e.record()
             ev.append((s, e, block.nnz, block.n_rows))
         else:
-            hip_ops.spmm_raw(block, X, Y=Y)
+            hip_ops.spmm_raw(block, X, Y=Y, **ep)
 
+    prop = None
     if not multi:
         def step():
             cur = X0
@@ -426,13 +529,26 @@ def main():
         prop = ShardedPropagator(sh, ublk, iblk, rank, local_spmm, force_collectives=multi)
 
         def step():
-            prop.propagate(X0, N_LAYERS, bufs=bufs)
+            prop.propagate(X0, N_LAYERS, bufs=bufs)     # ping-pong: only the last layer is kept, as a model would
 
     def fence():
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed_steps(fn, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        t = time.perf_counter() - t0
+        if multi:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
 
     for _ in range(args.warmup):
         step()
@@ -443,20 +559,47 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     timed = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(step, args.steps)
     timed = False
-    if multi:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    # N > 1: also time the no-exchange alternative (one full replica per GPU) after the timed region
-    replicas_rate = None
+    # N > 1: what the exchange costs and how much of it hides under the SpMMs (allgather layout), the nnz balance
+    # of the cut, the no-exchange alternative (one full replica per GPU), a weak-scaling companion and a sharded
+    # training step -- all AFTER the timed region
+    dist_extra = None
     if multi:
+        dist_extra = {}
+        if args.layout == "allgather":
+            per_rank = sh.nnz_per_rank(r)
+            dist_extra["nnz_per_rank"] = [int(x) for x in per_rank]
+            dist_extra["nnz_imbalance_max_over_mean"] = float(per_rank.max() / per_rank.mean())
+            dist_extra["chunks_per_rank"] = sh.n_chunks
+            b0 = prop.op.bytes_gathered
+            step()
+            fence()
+            inbound = prop.op.bytes_gathered - b0                     # payload bytes this rank received per step
+            compute_only = ShardedPropagator(sh, ublk, iblk, rank, local_spmm)
+            compute_only.op.exchange = False
+            t_comp = timed_steps(lambda: compute_only.propagate(X0, N_LAYERS, bufs=bufs), args.steps) / args.steps
+
+            def comm_only():
+                for layer in range(N_LAYERS):
+                    works = []
+                    for _, lo, hi, rlo, rhi in prop.op.entries:
+                        works.append(dist.all_gather_into_tensor(bufs[layer % 2][rlo:rhi], bufs[layer % 2][lo:hi],
+                                                                 async_op=True))
+                    for w in works:
+                        w.wait()
+            comm_only()
+            t_comm = timed_steps(comm_only, args.steps) / args.steps
+            t_tot = dt / args.steps
+            dist_extra.update({
+                "exchange_bytes_in_per_rank_per_step": int(inbound),
+                "ms_per_step_compute_only": t_comp * 1e3, "ms_per_step_exchange_only": t_comm * 1e3,
+                "xgmi_gbps_achieved": inbound / t_tot / 1e9,            # per GPU, inbound, inside the timed step
+                "xgmi_gbps_exchange_only": inbound / t_comm / 1e9,      # the same all-gathers with nothing else running
+                "overlap_frac": max(0.0, min(1.0, (t_comp + t_comm - t_tot) / max(min(t_comp, t_comm), 1e-9))),
+                "note_exchange": "per-GPU inbound payload of the per-layer all-gathers (fp32 rows); overlap_frac = share of "
+                                 "the shorter of {SpMMs, exchange} that ran hidden under the other"})
         full = hip_ops.CsrGraph.from_coo_device(
             torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
             torch.from_numpy(v).to(dev), n_nodes, n_nodes, symmetric=True)
@@ -470,43 +613,51 @@ def main():
                 cur = nxts[layer % 2]
         for _ in range(2):
             rep_step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            rep_step()
-        fence()
-        tr = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-        replicas_rate = world * nnz_total * N_LAYERS * args.steps / float(tr.item())
+        dist_extra["replicas_edges_per_s"] = world * nnz_total * N_LAYERS * args.steps / timed_steps(rep_step, args.steps)
         del full, xa, xb, xc
         # companions: a failure here (same code on every rank -> same exception on every rank) must not
         # cost the headline number
         try:
-            weak = weak_scaling_run(dev, rank, world, args.steps)
+            dist_extra["weak_scaling"] = weak_scaling_run(dev, rank, world, args.steps)
         except Exception as ex:
-            weak = {"error": repr(ex)}
-        try:
-            train = (sharded_train_run(dev, rank, world, sh, ublk, iblk, args.steps)
-                     if args.layout == "allreduce" else None)
-        except Exception as ex:
-            train = {"error": repr(ex)}
+            dist_extra["weak_scaling"] = {"error": repr(ex)}
+        if args.layout == "allreduce":
+            try:
+                dist_extra["sharded_train_step"] = sharded_train_run(dev, rank, world, sh, ublk, iblk, args.steps)
+            except Exception as ex:
+                dist_extra["sharded_train_step"] = {"error": repr(ex)}
+        dist_extra["note"] = ("replicas = every GPU propagates its own full copy of the graph (how MMRec uses several "
+                              "GPUs: independent hyper-parameter runs); `value` is the sharded layout named in "
+                              "config.parallelism")
 
     # roofline of the dominant kernel family (one SpMM call), from the events of this rank
     call_ms = np.array([s.elapsed_time(e) for s, e, _, _ in ev])
-    call_bytes = np.array([alg_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
-    achieved = float(call_bytes.sum() / (call_ms.sum() * 1e-3) / 1e9)
+    call_alg = np.array([alg_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
+    call_min = np.array([alg_compulsory_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
+    ms_launch = float(call_ms.mean())
+    alg_gbs = float(call_alg.sum() / (call_ms.sum() * 1e-3) / 1e9)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "spmm_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+    if rank == 0 and not multi:
+        traffic = (None if args.no_pmc else measure_traffic(g, n_nodes)) or committed_traffic()
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "kernel": "mmrec_spmm_csr_f32 (spmm_rows_kernel + long-row chunk/reduce kernels)",
-                "alg_bytes_per_launch": float(call_bytes.mean()), "ms_per_launch": float(call_ms.mean()),
-                "launches_timed": int(len(ev))}
+                "ms_per_launch": ms_launch, "launches_timed": int(len(ev)),
+                "alg_bytes_per_launch": float(call_alg.mean()), "achieved_gather_model": alg_gbs,
+                "frac_gather_model": alg_gbs / HBM_PEAK_GBS,
+                "compulsory_bytes_per_launch": float(call_min.mean()),
+                "frac_compulsory": float(call_min.sum() / (call_ms.sum() * 1e-3) / 1e9) / HBM_PEAK_GBS}
+    if traffic is not None:      # headline: what the launch really moves past L2 (<= the fabric can carry: <= 1)
+        roofline.update({"achieved": traffic["bytes"] / (ms_launch * 1e-3) / 1e9,
+                         "frac": traffic["bytes"] / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic["bytes"], "traffic_fetch_bytes": traffic["fetch_bytes"],
+                         "traffic_write_bytes": traffic["write_bytes"], "l2_hit_rate": traffic["l2_hit_rate"],
+                         "traffic_source": traffic["source"],
+                         "definition": "achieved = (FETCH_SIZE x2 + WRITE_SIZE) per launch / ms_per_launch: bytes crossing "
+                                       "L2 -> Infinity Fabric (Infinity-Cache hits included); gather model and compulsory "
+                                       "bound alongside"})
+    else:                        # N > 1 ranks / no profiler and no committed profile: the gather model only
+        roofline.update({"achieved": alg_gbs, "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "definition": "gather model (no counters available in this run)"})
 
     if rank == 0:
         line = {
@@ -521,7 +672,7 @@ def main():
                        "parallelism": "single GPU" if not multi else
                        ("users sharded x%d, items replicated, RCCL all-reduce of item sums per layer" % world
                         if args.layout == "allreduce" else
-                        "row-sharded x%d, RCCL all-gather per layer" % world)},
+                        "rows sharded x%d (nnz-balanced, %d chunks/rank), RCCL all-gather per layer" % (world, sh.n_chunks))},
             "roofline": roofline,
         }
         if not multi and not args.no_cpu_baseline:
@@ -536,12 +687,7 @@ def main():
             except Exception as ex:  # the headline number must not be lost to an auxiliary failure
                 line["extra"] = {"error": repr(ex)}
         if multi:
-            line["extra"] = {"replicas_edges_per_s": replicas_rate, "weak_scaling": weak,
-                             "sharded_train_step": train,
-                             "note": "replicas = every GPU propagates its own full copy of the graph "
-                                     "(how MMRec uses several GPUs: independent hyper-parameter runs); "
-                                     "`value` is the sharded layout named in config.parallelism "
-                                     "(--layout allgather = the bit-exact all-gather-per-layer form)"}
+            line["extra"] = dist_extra
         print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()

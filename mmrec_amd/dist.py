@@ -2,11 +2,17 @@
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
 The normalised adjacency is bipartite: user rows read only item embeddings and item rows only user
-embeddings.  Rank r owns one contiguous block of users and one of items (equal-sized blocks over a
-padded id space, so the exchange is a plain all-gather), computes its rows of Y = A X with the HIP
-SpMM and the blocks are all-gathered so that every rank holds the next layer's X.  The user-block
-all-gather is issued asynchronously and overlaps the item-rows SpMM.  A row partition does not
+embeddings.  Rank r owns one contiguous block of users and one of items, cut so that every rank holds the
+same number of NONZEROS (not rows: SURVEY.md 8e), computes its rows of Y = A X with the HIP SpMM, and the
+blocks are all-gathered over RCCL after every layer so that each rank holds the next layer's X
+("all-gather of item embeddings ... after each GCN layer", BASELINE.json north_star).  A row partition does not
 change any row's summation order: sharded == single GPU bit for bit.
+
+Layout of the exchanged space.  Every rank's block is padded to the same capacity and cut into `n_chunks` row
+chunks; ids are laid out CHUNK-MAJOR (chunk c of every rank next to each other), so the all-gather of chunk c
+is one contiguous `all_gather_into_tensor`, issued as soon as the SpMM of chunk c is enqueued: it runs on RCCL's
+stream under the SpMM of chunk c + 1 (and the user chunks' exchange under the item rows' SpMMs).  Only the last
+chunk's exchange of a layer is exposed.
 
 fp32 on the wire (the 1e-4 parity target forbids a bf16 exchange).
 """
@@ -17,74 +23,221 @@ import torch
 import torch.distributed as dist
 
 
+# ------------------------------------------------------------------------------------------------
+# partition
+# ------------------------------------------------------------------------------------------------
+def balanced_cuts(weight, parts):
+    """Contiguous cut points [0 = c_0 <= c_1 <= ... <= c_parts = n] with ~equal sum(weight) per part."""
+    w = np.asarray(weight, dtype=np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for k in range(1, parts):
+        cuts.append(max(cuts[-1], int(np.searchsorted(cum, cum[-1] * k / parts, "left"))))
+    cuts.append(w.shape[0])
+    return np.asarray(cuts, dtype=np.int64)
+
+
+class RowSpace:
+    """n rows dealt to P ranks in contiguous blocks [cuts[r], cuts[r+1]); every block padded to `cap` rows
+    (a multiple of n_chunks), chunk-major positions starting at `base`:
+        row = cuts[r] + c * cb + o   ->   base + c * (P * cb) + r * cb + o          (cb = cap / n_chunks)."""
+
+    def __init__(self, n, world, weight=None, n_chunks=1, base=0):
+        self.n, self.P, self.n_chunks, self.base = int(n), int(world), int(n_chunks), int(base)
+        if weight is None:
+            per = -(-self.n // self.P)
+            self.cuts = np.minimum(np.arange(self.P + 1, dtype=np.int64) * per, self.n)
+        else:
+            assert len(weight) == self.n
+            self.cuts = balanced_cuts(weight, self.P)
+        big = int(np.diff(self.cuts).max()) if self.n else 0
+        self.cb = max(-(-big // self.n_chunks), 1)
+        self.cap = self.cb * self.n_chunks
+        self.size = self.P * self.cap
+        owner = np.repeat(np.arange(self.P, dtype=np.int64), np.diff(self.cuts))
+        local = np.arange(self.n, dtype=np.int64) - self.cuts[owner]
+        c, o = local // self.cb, local % self.cb
+        self.pos = self.base + c * (self.P * self.cb) + owner * self.cb + o     # row -> padded position
+
+    def block(self, rank):
+        return int(self.cuts[rank]), int(self.cuts[rank + 1])
+
+    def chunk_out(self, rank, c):
+        """padded positions [lo, hi) of chunk c of `rank`"""
+        lo = self.base + c * (self.P * self.cb) + rank * self.cb
+        return lo, lo + self.cb
+
+    def chunk_region(self, c):
+        """padded positions [lo, hi) of chunk c of ALL ranks (what one all-gather fills)"""
+        lo = self.base + c * (self.P * self.cb)
+        return lo, lo + self.P * self.cb
+
+
 class BipartiteSharding:
-    """Padded id space: user u -> u ; item i -> U_pad + i ; U_pad, I_pad multiples of world_size."""
+    """Users and items each dealt to P ranks (RowSpace); items sit behind the users: one padded space of
+    N_pad = U_pad + I_pad positions.  `user_weight` / `item_weight` (per-row nonzero counts) give nnz-balanced
+    blocks; without them blocks have equal row counts."""
 
-    def __init__(self, n_users, n_items, world_size):
-        self.n_users, self.n_items, self.P = int(n_users), int(n_items), int(world_size)
-        self.ub = -(-self.n_users // self.P)
-        self.ib = -(-self.n_items // self.P)
-        self.U_pad, self.I_pad = self.ub * self.P, self.ib * self.P
+    def __init__(self, n_users, n_items, world_size, user_weight=None, item_weight=None, n_chunks=1):
+        self.n_users, self.n_items, self.P, self.n_chunks = int(n_users), int(n_items), int(world_size), int(n_chunks)
+        self.users = RowSpace(n_users, world_size, user_weight, n_chunks, base=0)
+        self.items = RowSpace(n_items, world_size, item_weight, n_chunks, base=self.users.size)
+        self.ub, self.ib = self.users.cap, self.items.cap
+        self.U_pad, self.I_pad = self.users.size, self.items.size
         self.N_pad = self.U_pad + self.I_pad
+        self.pos = np.concatenate([self.users.pos, self.items.pos])        # node id (items offset by n_users) -> position
+        self._pos_t = {}
 
+    @classmethod
+    def from_coo(cls, rows, n_users, n_items, world_size, n_chunks=1):
+        """nnz-balanced: weights = nonzeros per row of the symmetric adjacency given by its COO row ids"""
+        deg = np.bincount(np.asarray(rows, dtype=np.int64), minlength=n_users + n_items)
+        return cls(n_users, n_items, world_size, deg[:n_users], deg[n_users:], n_chunks)
+
+    # -- contiguous blocks (n_chunks == 1 only)
     def user_rows(self, r):
-        return r * self.ub, (r + 1) * self.ub
+        assert self.n_chunks == 1
+        return self.users.chunk_out(r, 0)
 
     def item_rows(self, r):
-        return self.U_pad + r * self.ib, self.U_pad + (r + 1) * self.ib
+        assert self.n_chunks == 1
+        return self.items.chunk_out(r, 0)
+
+    def pos_tensor(self, device):
+        key = str(device)
+        if key not in self._pos_t:
+            self._pos_t[key] = torch.from_numpy(self.pos).to(device)
+        return self._pos_t[key]
+
+    def pad(self, x):
+        """[n_users + n_items, d] in node order -> [N_pad, d] (padding rows zero)"""
+        out = x.new_zeros(self.N_pad, x.shape[1])
+        out[self.pos_tensor(x.device)] = x
+        return out
 
     def pad_embeddings(self, user_emb, item_emb):
-        x = user_emb.new_zeros(self.N_pad, user_emb.shape[1])
-        x[:self.n_users] = user_emb
-        x[self.U_pad:self.U_pad + self.n_items] = item_emb
-        return x
+        return self.pad(torch.cat([user_emb, item_emb], 0))
+
+    def unpad_nodes(self, x):
+        return x[self.pos_tensor(x.device)]
 
     def unpad(self, x):
-        return x[:self.n_users], x[self.U_pad:self.U_pad + self.n_items]
+        y = self.unpad_nodes(x)
+        return y[:self.n_users], y[self.n_users:]
 
     def padded_coo(self, rows, cols):
         """Map node ids of the unpadded symmetric COO (items offset by n_users) into the padded space."""
-        off = self.U_pad - self.n_users
-        r = np.where(rows >= self.n_users, rows + off, rows)
-        c = np.where(cols >= self.n_users, cols + off, cols)
-        return r, c
+        return self.pos[np.asarray(rows, dtype=np.int64)], self.pos[np.asarray(cols, dtype=np.int64)]
+
+    def entries(self, rank):
+        """[(kind, chunk, out_lo, out_hi, reg_lo, reg_hi)] of this rank: user chunks first, then item chunks"""
+        out = []
+        for kind, sp in (("u", self.users), ("i", self.items)):
+            for c in range(sp.n_chunks):
+                out.append((kind, c) + sp.chunk_out(rank, c) + sp.chunk_region(c))
+        return out
+
+    def rank_blocks(self, rows, cols, vals, rank, make_csr):
+        """This rank's row chunks of the adjacency given as COO over NODE ids (items offset by n_users), any order:
+        -> (user chunk blocks, item chunk blocks), each `make_csr(local_rows, padded_cols, vals, n_rows, n_cols)`.
+        Entries keep their COO order inside a row (make_csr must be stable), so a row sums exactly as on one GPU."""
+        rows = np.asarray(rows, dtype=np.int64)
+        pr, pc = self.padded_coo(rows, cols)
+        vals = np.asarray(vals)
+        blocks = {"u": [], "i": []}
+        for kind, c, lo, hi, _, _ in self.entries(rank):
+            sel = np.nonzero((pr >= lo) & (pr < hi))[0]
+            blocks[kind].append(make_csr(pr[sel] - lo, pc[sel], vals[sel], hi - lo, self.N_pad))
+        return blocks["u"], blocks["i"]
+
+    def nnz_per_rank(self, rows):
+        owner_u = np.repeat(np.arange(self.P), np.diff(self.users.cuts))
+        owner_i = np.repeat(np.arange(self.P), np.diff(self.items.cuts))
+        owner = np.concatenate([owner_u, owner_i])
+        return np.bincount(owner[np.asarray(rows, dtype=np.int64)], minlength=self.P)
+
+
+def space_blocks(space, rows, cols, vals, rank, col_pos, n_cols, make_csr):
+    """Row chunks of a matrix whose ROWS live in `space` (a RowSpace; row ids 0..space.n) and whose column ids are
+    mapped through `col_pos` into a padded space of `n_cols` positions (item-item graphs: both are the item space)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    pr = space.pos[rows]
+    pc = col_pos[np.asarray(cols, dtype=np.int64)]
+    vals = np.asarray(vals)
+    out = []
+    for c in range(space.n_chunks):
+        lo, hi = space.chunk_out(rank, c)
+        sel = np.nonzero((pr >= lo) & (pr < hi))[0]
+        out.append(make_csr(pr[sel] - lo, pc[sel], vals[sel], hi - lo, n_cols))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded SpMM + chunked all-gather
+# ------------------------------------------------------------------------------------------------
+class RowShardedOp:
+    """out[own rows] = A_own @ X (+ epilogue) chunk by chunk, each chunk all-gathered as soon as it is enqueued.
+
+    entries: [(block, out_lo, out_hi, reg_lo, reg_hi)] -- positions are relative to the `out` tensor handed to
+    `apply`.  `local_spmm(block, X, Y, **epilogue)` is the HIP kernel (hip_ops.spmm_raw) in the product and a scipy
+    checker in the gloo tests; epilogue keys: Z, acc_in, acc_out (row slices), alpha, beta, acc_scale."""
+
+    def __init__(self, entries, local_spmm, group=None, exchange=True):
+        self.entries, self.local_spmm, self.group, self.exchange = list(entries), local_spmm, group, exchange
+        self.bytes_gathered = 0     # payload this rank RECEIVED through the all-gathers (metrics)
+
+    def apply(self, X, out, Z=None, acc_in=None, acc_out=None, gather_acc=False, write_y=True, **scal):
+        """Per entry: Y = out[o], optional Z[o] / acc_in[o] / acc_out[o] slices; the gathered tensor is `acc_out`
+        when gather_acc else `out`.  Returns the list of pending collectives (call `.wait()` on each)."""
+        works = []
+        target = acc_out if gather_acc else out
+        for blk, lo, hi, rlo, rhi in self.entries:
+            ep = dict(scal)
+            if Z is not None:
+                ep["Z"] = Z[lo:hi]
+            if acc_out is not None:
+                ep["acc_in"], ep["acc_out"] = acc_in[lo:hi], acc_out[lo:hi]
+            y = out[lo:hi] if write_y else None
+            if ep:
+                self.local_spmm(blk, X, y, **ep)
+            else:
+                self.local_spmm(blk, X, y)
+            if self.exchange:
+                works.append(dist.all_gather_into_tensor(target[rlo:rhi], target[lo:hi], group=self.group, async_op=True))
+                self.bytes_gathered += (rhi - rlo - (hi - lo)) * target.shape[1] * target.element_size()
+        return works
+
+    def run(self, X, out, **kw):
+        for w in self.apply(X, out, **kw):
+            w.wait()
+        return out
 
 
 class ShardedPropagator:
-    """L-layer LightGCN propagation with rows sharded over `group`.
+    """L-layer LightGCN propagation with the rows of the bipartite adjacency sharded over `group`.
 
-    `local_spmm(block, X, Y)` computes Y[:block.n_rows] = A_block @ X; the product passes the HIP
-    kernel (hip_ops.spmm_raw); the gloo CPU test passes a checker so that the partition/exchange
-    logic can be verified without a GPU."""
+    user_blocks / item_blocks: this rank's row chunks (BipartiteSharding.rank_blocks; a single block is accepted
+    for n_chunks == 1).  `local_spmm(block, X, Y, **epilogue)` computes Y[:block.n_rows] = A_block @ X."""
 
-    def __init__(self, sharding, user_block, item_block, rank, local_spmm, group=None,
-                 force_collectives=False):
+    def __init__(self, sharding, user_blocks, item_blocks, rank, local_spmm, group=None, force_collectives=False):
         self.sh, self.rank, self.group = sharding, rank, group
-        self.force_collectives = force_collectives   # run the exchange even at world size 1 (tests)
-        self.user_block, self.item_block = user_block, item_block
-        self.local_spmm = local_spmm
+        ub = list(user_blocks) if isinstance(user_blocks, (list, tuple)) else [user_blocks]
+        ib = list(item_blocks) if isinstance(item_blocks, (list, tuple)) else [item_blocks]
+        assert len(ub) == sharding.n_chunks and len(ib) == sharding.n_chunks
+        self.exchange = sharding.P > 1 or force_collectives   # run the exchange even at world size 1 (tests)
+        blocks = ub + ib
+        self.op = RowShardedOp([(blk,) + e[2:] for blk, e in zip(blocks, sharding.entries(rank))], local_spmm, group,
+                               self.exchange)
 
     def layer(self, X, X_next):
         """X_next = A @ X for the full (padded) id space; returns X_next."""
-        sh = self.sh
-        u0, u1 = sh.user_rows(self.rank)
-        i0, i1 = sh.item_rows(self.rank)
-        yu, yi = X_next[u0:u1], X_next[i0:i1]
-        self.local_spmm(self.user_block, X, yu)
-        if sh.P == 1 and not self.force_collectives:
-            self.local_spmm(self.item_block, X, yi)
-            return X_next
-        hu = dist.all_gather_into_tensor(X_next[:sh.U_pad], yu, group=self.group, async_op=True)
-        self.local_spmm(self.item_block, X, yi)  # overlaps the user-block exchange
-        hi = dist.all_gather_into_tensor(X_next[sh.U_pad:], yi, group=self.group, async_op=True)
-        hu.wait()
-        hi.wait()
-        return X_next
+        return self.op.run(X, X_next)
 
     def propagate(self, X0, n_layers, bufs=None):
-        """Runs n_layers layers; returns the list [X1..XL] views (double-buffered unless bufs given)."""
+        """Runs n_layers layers; returns [X1..XL] (one buffer per layer unless `bufs` are given: with fewer than
+        n_layers buffers earlier outputs are overwritten, which callers that only need the last layer may ask for)."""
         if bufs is None:
-            bufs = [torch.empty_like(X0) for _ in range(min(n_layers, 2))]
+            bufs = [torch.empty_like(X0) for _ in range(n_layers)]
         cur, outs = X0, []
         for layer in range(n_layers):
             nxt = bufs[layer % len(bufs)]
@@ -94,6 +247,110 @@ class ShardedPropagator:
         return outs
 
 
+class _ShardedLightGCNMean(torch.autograd.Function):
+    """mean_l(A^l E0), l = 0..L, over the sharded rows: hip_ops._LightGCNMean with an all-gather after every layer.
+    The layer sum rides in the SpMM epilogue on the rank's own rows; the LAST layer gathers the mean itself, so
+    forward and backward each move L all-gathers.  E0 and the result are replicated [N, d] tensors in node order
+    (every rank computes the same loss on them, so the incoming gradient is replicated too); per-row arithmetic is
+    the single-GPU kernel's: results are bit-identical to hip_ops.lightgcn_mean on the unsharded graph."""
+
+    @staticmethod
+    def forward(ctx, E0, prop, n_layers):
+        sh, L = prop.sh, int(n_layers)
+        ctx.prop, ctx.L = prop, L
+        if L == 0:
+            return E0.clone()
+        X0 = sh.pad(E0.contiguous())
+        acc = torch.zeros_like(X0)
+        bufs = [torch.empty_like(X0) if L > 1 else None, torch.empty_like(X0) if L > 2 else None]
+        cur = X0
+        for layer in range(1, L + 1):
+            last = layer == L
+            nxt = acc if last else bufs[(layer - 1) % 2]
+            prop.op.run(cur, nxt, acc_in=X0 if layer == 1 else acc, acc_out=acc, gather_acc=last, write_y=not last,
+                        acc_scale=1.0 / (L + 1) if last else 1.0)
+            cur = nxt
+        return sh.unpad_nodes(acc)
+
+    @staticmethod
+    def backward(ctx, dOut):
+        prop, L, sh = ctx.prop, ctx.L, ctx.prop.sh
+        if L == 0:
+            return dOut, None, None
+        s = 1.0 / (L + 1)
+        G = sh.pad(dOut.contiguous())
+        bufs = [torch.empty_like(G), torch.empty_like(G) if L > 1 else None]
+        t = G
+        for j in range(L):       # t <- s G + A^T t  (A symmetric; the first step also scales the inner term)
+            out = bufs[j % 2]
+            prop.op.run(t, out, Z=G, alpha=s if j == 0 else 1.0, beta=s)
+            t = out
+        return sh.unpad_nodes(t), None, None
+
+
+def sharded_lightgcn_mean(prop: ShardedPropagator, E0, n_layers):
+    return _ShardedLightGCNMean.apply(E0, prop, n_layers)
+
+
+class ShardedSquareMatrix:
+    """A square matrix over ONE row space (FREEDOM's frozen item-item graph over the item space) with its rows sharded
+    like that space: forward = rows of A, backward = rows of A^T (the graph is directed), both all-gathered."""
+
+    def __init__(self, space, fwd_blocks, bwd_blocks, rank, local_spmm, group=None, force_collectives=False):
+        self.space = space
+        ex = space.P > 1 or force_collectives
+        ent = [(space.chunk_out(rank, c)[0] - space.base, space.chunk_out(rank, c)[1] - space.base,
+                space.chunk_region(c)[0] - space.base, space.chunk_region(c)[1] - space.base)
+               for c in range(space.n_chunks)]
+        self.fwd = RowShardedOp([(b,) + e for b, e in zip(fwd_blocks, ent)], local_spmm, group, ex)
+        self.bwd = RowShardedOp([(b,) + e for b, e in zip(bwd_blocks, ent)], local_spmm, group, ex)
+        self._pos_t = {}
+
+    def pos_tensor(self, device):
+        key = str(device)
+        if key not in self._pos_t:
+            self._pos_t[key] = torch.from_numpy(self.space.pos - self.space.base).to(device)
+        return self._pos_t[key]
+
+    def pad(self, x):
+        out = x.new_zeros(self.space.size, x.shape[1])
+        out[self.pos_tensor(x.device)] = x
+        return out
+
+    def unpad(self, x):
+        return x[self.pos_tensor(x.device)]
+
+
+class _ShardedSpMM(torch.autograd.Function):
+    """A @ X + Z with A's rows sharded (ShardedSquareMatrix); X, Z and the result replicated, node order."""
+
+    @staticmethod
+    def forward(ctx, X, Z, mat):
+        ctx.mat, ctx.has_z = mat, Z is not None
+        Xp = mat.pad(X.contiguous())
+        out = torch.zeros_like(Xp)
+        mat.fwd.run(Xp, out, **({"Z": mat.pad(Z.contiguous()), "beta": 1.0} if Z is not None else {}))
+        return mat.unpad(out)
+
+    @staticmethod
+    def backward(ctx, dY):
+        mat = ctx.mat
+        dX = None
+        if ctx.needs_input_grad[0]:
+            Gp = mat.pad(dY.contiguous())
+            out = torch.zeros_like(Gp)
+            mat.bwd.run(Gp, out)
+            dX = mat.unpad(out)
+        return dX, (dY if ctx.has_z and ctx.needs_input_grad[1] else None), None
+
+
+def sharded_spmm(mat: ShardedSquareMatrix, X, Z=None):
+    return _ShardedSpMM.apply(X, Z, mat)
+
+
+# ------------------------------------------------------------------------------------------------
+# users sharded / items replicated (smaller exchange volume, not bit-exact)
+# ------------------------------------------------------------------------------------------------
 class ItemReplicatedPropagator:
     """Users sharded, items replicated ("1.5D"): the layout SURVEY.md 8(e) calls the smaller-volume
     variant, and the one the rest of the pipeline wants anyway (full-sort evaluation shards users and
@@ -151,11 +408,10 @@ class ItemReplicatedPropagator:
         return u_next, items_next
 
     def propagate(self, u_local, items, n_layers):
-        ub = [torch.empty_like(u_local) for _ in range(min(n_layers, 2))]
-        ib = [torch.empty_like(items) for _ in range(min(n_layers, 2))]
+        """-> [(U_1, I_1) .. (U_L, I_L)], one pair of buffers per layer (callers sum the layers)."""
         outs = []
-        for layer in range(n_layers):
-            u_local, items = self.layer(u_local, items, ub[layer % len(ub)], ib[layer % len(ib)])
+        for _ in range(n_layers):
+            u_local, items = self.layer(u_local, items, torch.empty_like(u_local), torch.empty_like(items))
             outs.append((u_local, items))
         return outs
 
@@ -304,6 +560,30 @@ def hip_local_linear(X, W, b):
         db = next(it) if bd is not None else None
         return dX, dW, db
     return Y.detach(), vjp
+
+
+class _OwnedRowsExchange(torch.autograd.Function):
+    """rows[b] of a [B, d] matrix are produced by the rank that OWNS row b's source (a batch item's projected
+    feature row is computed where the item's feature row lives); every rank needs all B rows (the loss is
+    replicated).  Forward: the ranks' disjoint contributions (zeros elsewhere) are summed by an all-reduce, which is
+    exact (x + 0) and, at B = 4096 rows x 64 floats = 1 MB, latency sized -- the degenerate all-to-all of 8 x 128 KB
+    pieces.  Backward: the replicated gradient is simply masked to the owned rows (every rank already holds it)."""
+
+    @staticmethod
+    def forward(ctx, rows_local, owned, group, multi):
+        ctx.owned = owned
+        out = rows_local * owned.unsqueeze(1).to(rows_local.dtype)
+        if multi:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.owned.unsqueeze(1).to(g.dtype), None, None, None
+
+
+def exchange_owned_rows(rows_local, owned_mask, group=None, multi=True):
+    return _OwnedRowsExchange.apply(rows_local, owned_mask, group, multi)
 
 
 def sharded_score_topk(Q_local, C, k, score_topk, mask_rowptr=None, mask_col=None, group=None, gather=True):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from mmrec_amd import hip_ops
 from mmrec_amd.common.lazy_rows import LazyRowEmbedding, lazy_adam_enabled
-from mmrec_amd.graph import knn_normalized_coo, norm_adj_graph, sparse_coo_to_graph
+from mmrec_amd.graph import knn_normalized_coo, mask_to_csr_device, norm_adj_graph, sparse_coo_to_graph
 from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
 
 
@@ -35,14 +35,20 @@ def build_mm_adj(v_feat, t_feat, knn_k, mm_image_weight, n_items):
     return torch.sparse_coo_tensor(idx, val, size)   # uncoalesced sum, like w*A_img + (1-w)*A_txt
 
 
-def load_or_build_mm_adj(config, v_feat, t_feat, knn_k, mm_image_weight, n_items, device, cache_name=None):
+def load_or_build_mm_coo(config, v_feat, t_feat, knn_k, mm_image_weight, n_items, cache_name=None, write=True):
+    """the frozen item-item graph as the torch sparse COO tensor the reference caches (loaded when the file exists)"""
     cache = os.path.join(os.path.abspath(config['data_path'] + config['dataset']),
                          cache_name or 'mm_adj_freedomdsp_{}_{}.pt'.format(knn_k, int(10 * mm_image_weight)))
     if os.path.exists(cache):
-        mm = torch.load(cache, weights_only=False)
-    else:
-        mm = build_mm_adj(v_feat, t_feat, knn_k, mm_image_weight, n_items)
+        return torch.load(cache, weights_only=False)
+    mm = build_mm_adj(v_feat, t_feat, knn_k, mm_image_weight, n_items)
+    if write:
         torch.save(mm.cpu(), cache)
+    return mm
+
+
+def load_or_build_mm_adj(config, v_feat, t_feat, knn_k, mm_image_weight, n_items, device, cache_name=None):
+    mm = load_or_build_mm_coo(config, v_feat, t_feat, knn_k, mm_image_weight, n_items, cache_name)
     g = sparse_coo_to_graph(mm, device)
     g.transpose()   # directed kNN graph: the backward needs A^T, built once (graph is frozen)
     return g
@@ -159,3 +165,244 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
             image_feats = hip_ops.linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
             mf_v = hip_ops.bpr_loss(ua, image_feats, users, pos_items, neg_items)
         return loss + self.reg_weight * (mf_t + mf_v)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# n_gpus > 1: the same model, one process per GPU (BASELINE config 5)
+# ------------------------------------------------------------------------------------------------------------------
+class _SumGradOverRanks(torch.autograd.Function):
+    """identity on a REPLICATED parameter whose gradient is produced in rank-local pieces (the projection weights: every
+    rank projects only the batch rows whose feature rows it owns): backward sums the pieces over the ranks, so that every
+    replica applies the same update."""
+
+    @staticmethod
+    def forward(ctx, p, group):
+        ctx.group = group
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as tdist
+        g = g.contiguous().clone()
+        if tdist.is_initialized() and tdist.get_world_size(ctx.group) > 1:
+            tdist.all_reduce(g, op=tdist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def _local_spmm(blk, X, Y, **ep):
+    return hip_ops.spmm_raw(blk, X, Y=Y, **ep)
+
+
+class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
+    """FREEDOM over `n_gpus` processes (torch.distributed initialised by the launcher; utils/quick_start.py does it from
+    the torchrun environment).  What is sharded and what is replicated:
+
+      * user-item graph (and its per-epoch pruned version): ROWS sharded, nnz-balanced (dist.BipartiteSharding); every
+        propagation layer = local HIP SpMM on the rank's row chunks + chunked RCCL all-gather (dist.sharded_lightgcn_mean)
+        -- forward and backward, bit-identical to the single-GPU kernel;
+      * frozen item-item graph: rows sharded like the items (dist.sharded_spmm);
+      * id embedding tables: replicated parameters with replicated gradients (the loss is computed on replicated
+        tables from the same batch on every rank), identical fused-Adam updates: replicas stay bit-identical;
+      * raw feature tables (the 8.2 GB image table of config 5) and their Adam state: SHARDED by item block; a batch's
+        pos / neg rows are projected by their owners and exchanged as [2B, 64] rows (dist.exchange_owned_rows); the
+        projection weights are replicated, their partial gradients summed over ranks;
+      * evaluation: the propagation once (sharded), then every rank ranks its slice of the users against its replica of
+        the item table; the [users, k] ids are all-gathered (dist.sharded_score_topk).
+    Loaders, seeds and the negative sampler run identically on every rank (same batches everywhere).
+    Parameter names are FREEDOM's; `image_embedding.weight` / `text_embedding.weight` hold the rank's rows only
+    (`gather_feature_tables()` rebuilds the full tables)."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        import torch.distributed as tdist
+        from mmrec_amd.dist import BipartiteSharding, ShardedPropagator, ShardedSquareMatrix, space_blocks
+        from mmrec_amd.graph import sym_norm_coo, unique_edges
+        if not tdist.is_initialized():
+            raise RuntimeError('ShardedFREEDOM needs torch.distributed (launch with torchrun; config n_gpus)')
+        self.group = None
+        self.rank, self.world = tdist.get_rank(), tdist.get_world_size()
+        self.force = bool(config['dist_force_collectives'])     # testing aid: run the collectives at world size 1 too
+        self.embedding_dim = config['embedding_size']
+        self.feat_embed_dim = config['feat_embed_dim']
+        self.knn_k = config['knn_k']
+        self.n_layers = config['n_mm_layers']
+        self.n_ui_layers = config['n_ui_layers']
+        self.reg_weight = config['reg_weight']
+        self.mm_image_weight = config['mm_image_weight']
+        self.dropout = config['dropout']
+        n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
+        self.lazy_feature_adam = lazy_adam_enabled(config, n_feat)
+        self.graph_capturable = False
+        nu, ni = self.n_users, self.n_items
+        self.n_nodes = nu + ni
+
+        self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
+        eu, ei = unique_edges(self.interaction_matrix.row, self.interaction_matrix.col, ni)
+        r, c, v = sym_norm_coo(eu, ei, nu, ni)
+        chunks = config['dist_chunks']
+        if not chunks:      # a chunk should stay a >= ~2.5M-nnz SpMM, else launches dominate
+            chunks = int(min(4, max(1, r.shape[0] // self.world // 2_500_000)))
+        self.sharding = sh = BipartiteSharding.from_coo(r, nu, ni, self.world, n_chunks=chunks)
+        self.nnz_per_rank = sh.nnz_per_rank(r)
+        make = lambda lr, pc, vals, n_rows, n_cols: hip_ops.CsrGraph.from_coo_host(  # noqa: E731
+            np.stack([lr, pc]), vals, n_rows, n_cols, self.device)
+        ub, ib = sh.rank_blocks(r, c, v, self.rank, make)
+        self.norm_prop = ShardedPropagator(sh, ub, ib, self.rank, _local_spmm, group=self.group, force_collectives=self.force)
+        self.masked_prop = None
+        rows = torch.from_numpy(self.interaction_matrix.row.astype(np.int64))
+        cols = torch.from_numpy(self.interaction_matrix.col.astype(np.int64))
+        self.edge_indices = torch.stack([rows, cols]).to(self.device)
+        self.edge_values = hip_ops.edge_norm_values(self.edge_indices[0].contiguous(), self.edge_indices[1].contiguous(),
+                                                    nu, ni)
+
+        # parameters in FREEDOM's construction order (same generator consumption -> same initial values)
+        self.user_embedding = nn.Embedding(nu, self.embedding_dim)
+        self.item_id_embedding = nn.Embedding(ni, self.embedding_dim)
+        nn.init.xavier_uniform_(self.user_embedding.weight)
+        nn.init.xavier_uniform_(self.item_id_embedding.weight)
+        self.item_lo, self.item_hi = sh.items.block(self.rank)
+        table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
+
+        def local_rows(feat):
+            rows_ = feat[self.item_lo:self.item_hi]
+            return rows_.clone() if rows_.shape[0] else feat.new_zeros(1, feat.shape[1])   # an empty block owns nothing
+        if self.v_feat is not None:
+            self.image_embedding = table.from_pretrained(local_rows(self.v_feat), freeze=False)
+            self.image_trs = nn.Linear(self.v_feat.shape[1], self.feat_embed_dim)
+        if self.t_feat is not None:
+            self.text_embedding = table.from_pretrained(local_rows(self.t_feat), freeze=False)
+            self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
+
+        mm = load_or_build_mm_coo(config, self.v_feat, self.t_feat, self.knn_k, self.mm_image_weight, ni,
+                                  write=self.rank == 0)
+        idx, val = mm._indices().cpu().numpy(), mm._values().cpu().numpy().astype(np.float32)
+        order = np.argsort(idx[0], kind='stable')            # the single-GPU CSR order (transpose() starts from it)
+        idx, val = idx[:, order], val[order]
+        ipos = sh.items.pos - sh.items.base
+        make_i = lambda lr, pc, vals, n_rows, n_cols: hip_ops.CsrGraph.from_coo_host(  # noqa: E731
+            np.stack([lr, pc]), vals, n_rows, n_cols, self.device)
+        fwd = space_blocks(sh.items, idx[0], idx[1], val, self.rank, ipos, sh.items.size, make_i)
+        bwd = space_blocks(sh.items, idx[1], idx[0], val, self.rank, ipos, sh.items.size, make_i)
+        self.mm_adj = ShardedSquareMatrix(sh.items, fwd, bwd, self.rank, _local_spmm, group=self.group,
+                                          force_collectives=self.force)
+        self.v_feat_dim = None if self.v_feat is None else self.v_feat.shape[1]
+        # the full tables are only needed up to here (kNN graph + this rank's rows)
+        if config['dist_keep_full_features'] is not True:
+            self.v_feat = None if self.v_feat is None else self.v_feat[:0]
+            self.t_feat = None if self.t_feat is None else self.t_feat[:0]
+
+    # ---- per-epoch pruned graph: rank 0 draws, everybody builds its own rows
+    def pre_epoch_processing(self):
+        import torch.distributed as tdist
+        if self.dropout <= .0:
+            self.masked_prop = self.norm_prop
+            return
+        keep_len = int(self.edge_values.size(0) * (1. - self.dropout))
+        keep = torch.multinomial(self.edge_values, keep_len)     # every rank draws (generators stay aligned) ...
+        if self.world > 1:                                        # ... and rank 0's draw is the one everybody uses
+            tdist.broadcast(keep, src=0, group=self.group)
+        self.set_kept_edges(keep)
+
+    def set_kept_edges(self, keep_idx):
+        from mmrec_amd.dist import ShardedPropagator
+        sh, nu = self.sharding, self.n_users
+        kept = self.edge_indices[:, keep_idx]
+        eu, ei = kept[0].contiguous(), kept[1].contiguous()
+        w = hip_ops.edge_norm_values(eu, ei, nu, self.n_items)
+        rows, cols, vals = torch.cat((eu, ei + nu)), torch.cat((ei + nu, eu)), torch.cat((w, w))   # freedom.py:139-143
+        pos = sh.pos_tensor(rows.device)
+        pr, pc = pos[rows], pos[cols]
+        blocks = []
+        for _, _, lo, hi, _, _ in sh.entries(self.rank):
+            sel = (pr >= lo) & (pr < hi)
+            blocks.append(hip_ops.CsrGraph.from_coo_device((pr[sel] - lo).to(torch.int32).contiguous(),
+                                                           pc[sel].to(torch.int32).contiguous(), vals[sel].contiguous(),
+                                                           hi - lo, sh.N_pad))
+        nc = sh.n_chunks
+        self.masked_prop = ShardedPropagator(sh, blocks[:nc], blocks[nc:], self.rank, _local_spmm, group=self.group,
+                                             force_collectives=self.force)
+
+    def forward(self, prop):
+        from mmrec_amd.dist import sharded_lightgcn_mean, sharded_spmm
+        ego = torch.cat((self.user_embedding.weight, self.item_id_embedding.weight), dim=0)
+        mean = sharded_lightgcn_mean(prop, ego, self.n_ui_layers)
+        u_g, i_g = mean[:self.n_users], mean[self.n_users:]
+        h = self.item_id_embedding.weight
+        if self.n_layers == 0:
+            return u_g, i_g + h
+        for _ in range(self.n_layers - 1):
+            h = sharded_spmm(self.mm_adj, h)
+        return u_g, sharded_spmm(self.mm_adj, h, Z=i_g.contiguous())
+
+    def eval_embeddings(self):
+        return self.forward(self.norm_prop)
+
+    def _owned_projection(self, emb, trs, rows):
+        """[2B, 64] projected feature rows of the batch items, each computed by the rank that owns the item"""
+        from mmrec_amd.dist import exchange_owned_rows
+        owned = (rows >= self.item_lo) & (rows < self.item_hi)
+        local = torch.where(owned, rows - self.item_lo, torch.zeros_like(rows))
+        feats = emb.rows(local) if self.lazy_feature_adam else emb.weight[local]
+        w, b = _SumGradOverRanks.apply(trs.weight, self.group), _SumGradOverRanks.apply(trs.bias, self.group)
+        return exchange_owned_rows(hip_ops.linear(feats, w, b), owned, group=self.group, multi=self.world > 1 or self.force)
+
+    def calculate_loss(self, interaction):
+        users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
+        ua, ia = self.forward(self.masked_prop)
+        ua, ia = ua.contiguous(), ia.contiguous()
+        loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
+        rows = torch.cat((pos_items, neg_items))
+        b = pos_items.shape[0]
+        lp = torch.arange(b, device=rows.device)
+        ln = lp + b
+        mf_t = mf_v = 0.0
+        if self.t_feat is not None:
+            mf_t = hip_ops.bpr_loss(ua, self._owned_projection(self.text_embedding, self.text_trs, rows), users, lp, ln)
+        if self.v_feat is not None:
+            mf_v = hip_ops.bpr_loss(ua, self._owned_projection(self.image_embedding, self.image_trs, rows), users, lp, ln)
+        return loss + self.reg_weight * (mf_t + mf_v)
+
+    @torch.no_grad()
+    def full_sort_topk(self, interaction, k):
+        """every rank ranks its slice of the batch's users; ids all-gathered (no exchange in the scoring itself)"""
+        import torch.distributed as tdist
+        users, mask = interaction[0], interaction[1]
+        u, i = self._cached_eval_embeddings()
+        rowptr, cols = mask_to_csr_device(mask, users.shape[0], i.shape[0])
+        b = users.shape[0]
+        per = -(-b // self.world)
+        lo, hi = min(self.rank * per, b), min((self.rank + 1) * per, b)
+        out = torch.zeros(per, k, dtype=torch.int64, device=users.device)
+        if hi > lo:
+            rp = rowptr[lo:hi + 1]
+            s, e = int(rp[0]), int(rp[-1])
+            out[:hi - lo] = hip_ops.score_topk(u[users[lo:hi]].contiguous(), i, k, (rp - rp[0]).contiguous(),
+                                               cols[s:max(e, s + 1)].contiguous() if e > s else None)
+        if self.world == 1:
+            return out[:b]
+        full = torch.empty(self.world * per, k, dtype=torch.int64, device=users.device)
+        tdist.all_gather_into_tensor(full, out, group=self.group)
+        return full[:b]
+
+    @torch.no_grad()
+    def gather_feature_tables(self):
+        """-> {name: full [n_items, F] table} rebuilt from the ranks' blocks (collective; for export / state_dict)"""
+        import torch.distributed as tdist
+        from mmrec_amd.common.lazy_rows import flush_lazy_tables
+        flush_lazy_tables(self)
+        out, cuts = {}, self.sharding.items.cuts
+        for name in ('image_embedding', 'text_embedding'):
+            if not hasattr(self, name):
+                continue
+            w = getattr(self, name).weight
+            cap = int(np.diff(cuts).max())
+            buf = w.new_zeros(cap, w.shape[1])
+            n = self.item_hi - self.item_lo
+            buf[:n] = w[:n]
+            parts = [torch.empty_like(buf) for _ in range(self.world)]
+            if self.world > 1:
+                tdist.all_gather(parts, buf, group=self.group)
+            else:
+                parts = [buf]
+            out[name + '.weight'] = torch.cat([p[:int(cuts[r + 1] - cuts[r])] for r, p in enumerate(parts)], 0)
+        return out

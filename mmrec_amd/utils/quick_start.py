@@ -12,10 +12,42 @@ from .logger import init_logger
 from .utils import dict2str, eval_batch_size, get_model, get_trainer, init_seed
 
 
+def init_distributed(config_dict):
+    """New key `n_gpus` (default 1).  n_gpus > 1: this process is one rank of a `torchrun --nproc-per-node n_gpus`
+    launch (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); it takes GPU LOCAL_RANK.  Returns
+    (rank, world) -- the process group itself is created by `start_process_group` once the device is known."""
+    n = int((config_dict or {}).get('n_gpus') or 1)
+    if n <= 1:
+        return 0, 1
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != n:
+        raise RuntimeError('n_gpus={} needs one process per GPU: launch with `python -m torch.distributed.run --nnodes=1 '
+                           '--nproc-per-node {} --master-addr 127.0.0.1 ...` (WORLD_SIZE is {})'.format(n, n, world))
+    config_dict['gpu_id'] = int(os.environ.get('LOCAL_RANK', '0'))
+    return int(os.environ.get('RANK', '0')), world
+
+
+def start_process_group(config, rank, world):
+    import torch.distributed as tdist
+    if world <= 1 or tdist.is_initialized():
+        return
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes on this driver)
+    on_gpu = getattr(config['device'], 'type', 'cpu') == 'cuda'
+    tdist.init_process_group('nccl' if on_gpu else 'gloo', rank=rank, world_size=world,
+                             **({'device_id': config['device']} if on_gpu else {}))
+
+
 def quick_start(model, dataset, config_dict, save_model=True, mg=False):
+    config_dict = dict(config_dict or {})
+    rank, world = init_distributed(config_dict)
     config = Config(model, dataset, config_dict, mg)
     init_logger(config)
     logger = getLogger()
+    start_process_group(config, rank, world)
+    if rank > 0:
+        import logging
+        logger.setLevel(logging.WARNING)          # one log: rank 0's (all ranks compute the same losses / metrics)
     logger.info('██Server: \t' + platform.node())
     logger.info('██Dir: \t' + os.getcwd() + '\n')
     logger.info(config)
@@ -43,7 +75,7 @@ def quick_start(model, dataset, config_dict, save_model=True, mg=False):
         init_seed(config['seed'])
         logger.info('========={}/{}: Parameters:{}={}======='.format(idx + 1, len(grid), names, combo))
         train_data.pretrain_setup()
-        net = get_model(config['model'])(config, train_data).to(config['device'])
+        net = get_model(config['model'], sharded=world > 1)(config, train_data).to(config['device'])
         logger.info(net)
         trainer = get_trainer()(config, net, mg)
         _, best_valid, best_test = trainer.fit(train_data, valid_data=valid_data, test_data=test_data,

@@ -11,16 +11,19 @@ def get_local_time():
     return datetime.datetime.now().strftime('%b-%d-%Y-%H-%M-%S')
 
 
-def get_model(model_name):
+def get_model(model_name, sharded=False):
     """`FREEDOM` -> class FREEDOM in models/freedom.py.  Looks in a top-level `models` package first
-    (the reference layout, when these files are dropped into its src/) and then in mmrec_amd.models."""
+    (the reference layout, when these files are dropped into its src/) and then in mmrec_amd.models.
+    sharded (config `n_gpus` > 1): the module's `Sharded<Name>` class -- the same model over one process per GPU."""
     last_err = None
     for pkg in ('models', 'mmrec_amd.models'):
         try:
             module = importlib.import_module('{}.{}'.format(pkg, model_name.lower()))
-            return getattr(module, model_name)
+            return getattr(module, ('Sharded' if sharded else '') + model_name)
         except (ImportError, AttributeError) as err:
             last_err = err
+    if sharded:
+        raise ImportError('model {} has no multi-GPU (n_gpus > 1) variant Sharded{}: {}'.format(model_name, model_name, last_err))
     raise ImportError('model {} not found: {}'.format(model_name, last_err))
 
 

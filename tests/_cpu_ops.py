@@ -184,7 +184,7 @@ def linear(X, W, b=None):
     return F.linear(X, W, b)
 
 
-def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False):
+def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True):
     _mat(Q, "Q"), _mat(C, "C", width=Q.shape[1])
     assert Q.shape[1] % 4 == 0, "inner dim %d is not a multiple of 4" % Q.shape[1]
     if mask_rowptr is not None:
@@ -243,3 +243,15 @@ def cpu_ops(monkeypatch):
     for name in _PATCHED:
         monkeypatch.setattr(hip_ops, name, getattr(me, name))
     return me
+
+
+def install():
+    """the same swap, permanently, for a process that exists only for a test (torch.multiprocessing workers of the gloo
+    tests: pytest fixtures do not reach them)"""
+    import sys
+    from mmrec_amd import hip_ops
+    me = sys.modules[__name__]
+    for name in _PATCHED:
+        setattr(hip_ops, name, getattr(me, name))
+    return me
+

@@ -1,10 +1,12 @@
-"""CPU, world_size 2, gloo: the row-sharding + all-gather schedule of mmrec_amd.dist reproduces the
-single-process propagation bit for bit.  The local SpMM is a scipy checker here (the product passes
-the HIP kernel); this test is about partitioning and exchange, not about the kernel."""
+"""CPU, world_size 2 / 3, gloo: the row-sharding + chunked all-gather schedule of mmrec_amd.dist reproduces the
+single-process propagation bit for bit, forward and backward, and the sharded FREEDOM plugin (config `n_gpus`)
+reproduces the single-process plugin.  The local SpMM is a scipy checker here (the product passes the HIP kernel);
+these tests are about partitioning and exchange, not about the kernel."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import scipy.sparse as sp
 import torch
 import torch.distributed as dist
@@ -24,44 +26,128 @@ def _free_port():
     return p
 
 
-def _problem(world):
+def _scipy_csr(local_rows, cols, vals, n_rows, n_cols):
+    return sp.csr_matrix((vals, (local_rows, cols)), shape=(n_rows, n_cols), dtype=np.float32)
+
+
+def _problem(world, n_chunks=1, balanced=False):
     eu, ei = synth.powerlaw_edges(NU, NI, NE, seed=5)
     r, c, v = synth.sym_norm_coo(eu, ei, NU, NI)
-    sh = BipartiteSharding(NU, NI, world)
+    sh = BipartiteSharding.from_coo(r, NU, NI, world, n_chunks) if balanced else BipartiteSharding(NU, NI, world, n_chunks=n_chunks)
     rp, cp = sh.padded_coo(r, c)
     A = sp.csr_matrix((v, (rp, cp)), shape=(sh.N_pad, sh.N_pad), dtype=np.float32)
     g = torch.Generator().manual_seed(1)
     x0 = sh.pad_embeddings(torch.randn(NU, 64, generator=g), torch.randn(NI, 64, generator=g))
-    return sh, A, x0
+    return sh, A, x0, (r, c, v)
 
 
-def _local_spmm(block, X, Y):
-    Y.copy_(torch.from_numpy(block @ X.numpy()))
+def _local_spmm(block, X, Y, Z=None, acc_in=None, acc_out=None, alpha=1.0, beta=1.0, acc_scale=1.0):
+    """the epilogue contract of hip_ops.spmm_raw on a scipy block: Y = alpha A X + beta Z; acc_out = s (acc_in + Y)"""
+    y = torch.from_numpy(block @ X.numpy()) * np.float32(alpha)
+    if Z is not None:
+        y = y + np.float32(beta) * Z
+    if Y is not None:
+        Y.copy_(y)
+    if acc_out is not None:
+        acc_out.copy_(np.float32(acc_scale) * (acc_in + y))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, n_chunks, balanced):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sh, A, x0 = _problem(world)
-    u0, u1 = sh.user_rows(rank)
-    i0, i1 = sh.item_rows(rank)
-    prop = ShardedPropagator(sh, A[u0:u1], A[i0:i1], rank, _local_spmm)
-    outs = prop.propagate(x0, L, bufs=[torch.empty_like(x0) for _ in range(L)])
+    sh, A, x0, _ = _problem(world, n_chunks, balanced)
+    ent = sh.entries(rank)
+    blocks = [A[lo:hi] for _, _, lo, hi, _, _ in ent]          # rows of the full padded matrix: same per-row order
+    nc = sh.n_chunks
+    prop = ShardedPropagator(sh, blocks[:nc], blocks[nc:], rank, _local_spmm)
+    outs = prop.propagate(x0, L)
     if rank == 0:
         torch.save([o.clone() for o in outs], out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_equals_single(tmp_path):
+@pytest.mark.parametrize("world,n_chunks,balanced", [(2, 1, False), (2, 2, True), (3, 3, True)])
+def test_sharded_equals_single(tmp_path, world, n_chunks, balanced):
+    """equal-row and nnz-balanced blocks, 1..3 chunks per rank (chunk-major padded space, one all-gather per chunk)"""
     out = str(tmp_path / "outs.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, n_chunks, balanced), nprocs=world, join=True)
     got = torch.load(out)
-    sh, A, x0 = _problem(2)
+    sh, A, x0, _ = _problem(world, n_chunks, balanced)
     cur = x0.numpy()
     for layer in range(L):
         cur = A @ cur
         assert np.array_equal(got[layer].numpy(), cur), "layer %d differs" % layer
+
+
+def test_rank_blocks_partition_the_adjacency_nnz_balanced():
+    """BipartiteSharding.from_coo: contiguous user / item blocks with ~equal nonzeros per rank, and
+    rank_blocks() = exactly the rank's rows of the padded matrix (every nonzero in exactly one block)."""
+    eu, ei = synth.powerlaw_edges(400, 150, 5000, seed=2, zipf=1.1)      # strongly skewed items
+    r, c, v = synth.sym_norm_coo(eu, ei, 400, 150)
+    for world, n_chunks in ((2, 1), (3, 2), (8, 4)):
+        sh = BipartiteSharding.from_coo(r, 400, 150, world, n_chunks)
+        rp, cp = sh.padded_coo(r, c)
+        assert len(np.unique(sh.pos)) == 550 and sh.pos.max() < sh.N_pad
+        A = sp.csr_matrix((v, (rp, cp)), shape=(sh.N_pad, sh.N_pad), dtype=np.float32)
+        total = 0
+        for rank in range(world):
+            ub, ib = sh.rank_blocks(r, c, v, rank, _scipy_csr)
+            for blk, (_, _, lo, hi, rlo, rhi) in zip(ub + ib, sh.entries(rank)):
+                assert (blk != A[lo:hi]).nnz == 0 and rlo <= lo and hi <= rhi
+                total += blk.nnz
+        assert total == A.nnz
+        per = sh.nnz_per_rank(r)
+        eq = BipartiteSharding(400, 150, world).nnz_per_rank(r)
+        assert per.sum() == r.shape[0] and per.max() / per.mean() <= eq.max() / eq.mean() + 1e-9
+        assert per.max() / per.mean() < 1.25, per
+
+
+# ---- the autograd layer mean over sharded rows == the single-process one, forward and backward ------------------
+def _worker_mean(rank, world, port, out):
+    from mmrec_amd.dist import sharded_lightgcn_mean
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh, A, _, _ = _problem(world, 2, True)
+    ent = sh.entries(rank)
+    blocks = [A[lo:hi] for _, _, lo, hi, _, _ in ent]
+    prop = ShardedPropagator(sh, blocks[:2], blocks[2:], rank, _local_spmm)
+    g = torch.Generator().manual_seed(3)
+    E0 = torch.randn(NU + NI, 64, generator=g).requires_grad_()
+    Wt = torch.randn(NU + NI, 64, generator=g)
+    res = {}
+    for layers in (1, 2, 3):
+        E0.grad = None
+        mean = sharded_lightgcn_mean(prop, E0, layers)
+        (mean * Wt).sum().backward()          # the same (replicated) loss on every rank
+        res[layers] = (mean.detach().clone(), E0.grad.clone())
+    if rank == world - 1:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lightgcn_mean_forward_backward(tmp_path, world):
+    out = str(tmp_path / "mean.pt")
+    mp.spawn(_worker_mean, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = torch.load(out)
+    eu, ei = synth.powerlaw_edges(NU, NI, NE, seed=5)
+    r, c, v = synth.sym_norm_coo(eu, ei, NU, NI)
+    A = torch.sparse_coo_tensor(torch.as_tensor(np.stack([r, c])), torch.as_tensor(v), (NU + NI, NU + NI)).coalesce()
+    g = torch.Generator().manual_seed(3)
+    E0 = torch.randn(NU + NI, 64, generator=g).requires_grad_()
+    Wt = torch.randn(NU + NI, 64, generator=g)
+    for layers in (1, 2, 3):
+        E0.grad = None
+        cur, acc = E0, E0
+        for _ in range(layers):
+            cur = torch.sparse.mm(A, cur)
+            acc = acc + cur
+        mean = acc / (layers + 1)
+        (mean * Wt).sum().backward()
+        np.testing.assert_allclose(res[layers][0].numpy(), mean.detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(res[layers][1].numpy(), E0.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
 # ---- users sharded / items replicated layout (all-reduce of item partial sums) -----------------
@@ -312,16 +398,79 @@ def test_bench_multi_gpu_blocks_partition_the_graph(monkeypatch):
         items_sum += rt_blk.matmul(X[u0:u1])                         # partial of I' = sum_r R_r^T U_r
     np.testing.assert_allclose(torch.cat(user_rows).numpy(), ref[:nu].numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(items_sum.numpy(), ref[nu:].numpy(), rtol=1e-5, atol=1e-6)
-    # rows sharded over the padded id space
+    # rows sharded (nnz-balanced cut, two chunks per rank) over the chunk-major padded id space
     Xp = None
     out = None
     for rank in range(world):
-        sh, _, ublk, iblk, *_ = bench.build_c5("cpu", rank, world, "allgather", True)
+        sh, _, ublocks, iblocks, *_ = bench.build_c5("cpu", rank, world, "allgather", True, 2)
         if Xp is None:
             Xp, out = sh.pad_embeddings(X[:nu], X[nu:]), torch.zeros(sh.N_pad, 64)
-        (a0, a1), (b0, b1) = sh.user_rows(rank), sh.item_rows(rank)
-        out[a0:a1] = ublk.matmul(Xp)
-        out[b0:b1] = iblk.matmul(Xp)
+        for blk, (_, _, lo, hi, _, _) in zip(ublocks + iblocks, sh.entries(rank)):
+            out[lo:hi] = blk.matmul(Xp)
     uo, io = sh.unpad(out)
     np.testing.assert_allclose(uo.numpy(), ref[:nu].numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(io.numpy(), ref[nu:].numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ---- config `n_gpus`: the sharded FREEDOM plugin through the Trainer == the single-process plugin -------------------
+def _freedom_run(root, golden, world):
+    """two epochs of Trainer on the golden tiny dataset (edge dropout 0.8, both modalities) -> per-epoch losses, the
+    parameters, the feature tables and the validation metrics"""
+    from mmrec_amd.common.trainer import Trainer
+    from mmrec_amd.utils.utils import get_model
+    from tests._env import setup
+    extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "n_gpus": world, "dist_chunks": 2}
+    config, train_data, valid_data = setup(root, golden, "FREEDOM", extra, use_gpu=False)
+    model = get_model("FREEDOM", sharded=world > 1)(config, train_data)
+    trainer = Trainer(config, model)
+    losses = []
+    for epoch in range(2):
+        model.pre_epoch_processing()
+        loss, _ = trainer._train_epoch(train_data, epoch)
+        losses.append(float(loss))
+    metrics = trainer.evaluate(valid_data)
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    if world > 1:
+        params.update(model.gather_feature_tables())
+        params["_nnz_per_rank"] = torch.as_tensor(model.nnz_per_rank)
+    return losses, params, metrics
+
+
+def _worker_freedom(rank, world, port, root, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _cpu_ops
+    _cpu_ops.install()
+    golden = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny.npz")))
+    res = _freedom_run(os.path.join(root, "rank%d" % rank), golden, world)
+    torch.save(res, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_freedom_plugin_matches_single_process(tmp_path, golden, cpu_ops, world):
+    """BASELINE config 5's model over `n_gpus` processes (row-sharded graphs + all-gather per layer, item-sharded feature
+    tables with the batch's projected rows exchanged, replicated id tables): same batches, same injected draws (the
+    per-epoch multinomial is rank 0's), two epochs of optimizer steps -> the single-process plugin's losses, parameters
+    (feature tables re-assembled from the shards) and metrics; every rank ends with the same replicated parameters."""
+    out = str(tmp_path / "freedom.pt")
+    mp.spawn(_worker_freedom, args=(world, _free_port(), str(tmp_path), out), nprocs=world, join=True)
+    got = [torch.load(out + ".%d" % r, weights_only=False) for r in range(world)]
+    losses, params, metrics = _freedom_run(str(tmp_path / "single"), golden, 1)
+    for r in range(world):
+        np.testing.assert_allclose(got[r][0], losses, rtol=1e-5)
+        assert got[r][2] == metrics
+        for name, ref in params.items():
+            # the projection biases cancel in <u, p> - <u, n>: their gradient is rounding noise of the summed terms, which
+            # Adam normalises into +-lr-sized steps whose signs depend on the summation order (single process too)
+            atol = 1e-4 if name.endswith("trs.bias") else 1e-6
+            np.testing.assert_allclose(got[r][1][name].numpy(), ref.numpy(), rtol=2e-4, atol=atol, err_msg=name)
+    for name in ("user_embedding.weight", "item_id_embedding.weight", "image_trs.weight"):
+        for r in range(1, world):
+            assert torch.equal(got[r][1][name], got[0][1][name]), name        # replicas stay bit-identical
+    nnz = got[0][1]["_nnz_per_rank"].numpy()
+    assert nnz.max() / nnz.mean() < 1.3
+
+
+from tests._cpu_ops import cpu_ops  # noqa: E402,F401  (fixture)

@@ -659,20 +659,75 @@ def test_sharded_propagator_rccl_single_rank(ops, dev):
         r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
         n = nu + ni
         full = ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
-        sh = BipartiteSharding(nu, ni, 1)
-        ub, ib = full.row_block(*sh.user_rows(0)), full.row_block(*sh.item_rows(0))
-        prop = ShardedPropagator(sh, ub, ib, 0, lambda blk, X, Y: ops.spmm_raw(blk, X, Y=Y),
+        # nnz-balanced cut, 3 row chunks per rank (chunk-major padded id space: one all-gather per chunk)
+        sh = BipartiteSharding.from_coo(r, nu, ni, 1, n_chunks=3)
+        make = lambda lr, pc, vals, nr, nc: ops.CsrGraph.from_coo_host(np.stack([lr, pc]), vals, nr, nc, dev)  # noqa: E731
+        ub, ib = sh.rank_blocks(r, c, v, 0, make)
+        prop = ShardedPropagator(sh, ub, ib, 0, lambda blk, X, Y, **ep: ops.spmm_raw(blk, X, Y=Y, **ep),
                                  force_collectives=True)
         gen = torch.Generator(device=dev).manual_seed(0)
         x0 = torch.rand(n, 64, device=dev, generator=gen) - 0.5
-        outs = prop.propagate(x0, 3, bufs=[torch.empty_like(x0) for _ in range(3)])
+        outs = prop.propagate(sh.pad(x0), 3)
         torch.cuda.synchronize()
         cur = x0
         for layer in range(3):
             y = torch.empty_like(x0)
             ops.spmm_raw(full, cur, Y=y)
-            assert torch.equal(outs[layer], y)
+            assert torch.equal(sh.unpad_nodes(outs[layer]), y)
             cur = y
+        # the autograd layer mean over the sharded rows (forward AND backward all-gathers) == hip_ops.lightgcn_mean, bitwise
+        from mmrec_amd.dist import sharded_lightgcn_mean
+        w = torch.rand(n, 64, device=dev, generator=gen) - 0.5
+        for layers in (1, 2, 3):
+            a, b = x0.clone().requires_grad_(), x0.clone().requires_grad_()
+            m1 = sharded_lightgcn_mean(prop, a, layers)
+            m2 = ops.lightgcn_mean(full, b, layers)
+            (m1 * w).sum().backward(), (m2 * w).sum().backward()
+            assert torch.equal(m1, m2) and torch.equal(a.grad, b.grad), layers
+        assert prop.op.bytes_gathered == 0          # world size 1: nothing is received
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev):
+    """config `n_gpus`: the sharded FREEDOM plugin (row-sharded graphs + RCCL all-gather per layer forward and backward,
+    item-sharded feature tables with the projected batch rows exchanged, sharded evaluation) on the HIP kernels through
+    a single-rank RCCL group, collectives forced: one epoch of Trainer steps and an evaluation == the plain FREEDOM
+    plugin (world sizes 2 / 3 run on gloo with the CPU stand-ins: tests/test_dist_gloo.py)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from mmrec_amd.common.trainer import Trainer
+    from mmrec_amd.utils.utils import get_model
+    from tests._env import setup
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        res = {}
+        for sharded in (False, True):
+            extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "dist_chunks": 2,
+                     "dist_force_collectives": True, "lazy_feature_adam": False}
+            config, train_data, valid_data = setup(tmp_path / ("s%d" % sharded), golden, "FREEDOM", extra, use_gpu=True)
+            model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(config["device"])
+            gen = torch.Generator().manual_seed(3)
+            keep = torch.multinomial(model.edge_values.detach().cpu(), int(model.edge_values.numel() * 0.2), generator=gen)
+            model.set_kept_edges(keep.to(dev))
+            trainer = Trainer(config, model)
+            loss, _ = trainer._train_epoch(train_data, 0)
+            metrics = trainer.evaluate(valid_data)
+            params = {n: p.detach().clone() for n, p in model.named_parameters()}
+            if sharded:
+                params.update(model.gather_feature_tables())
+            res[sharded] = (float(loss), metrics, params)
+        np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-5)
+        assert res[True][1] == res[False][1]
+        for name, ref in res[False][2].items():
+            atol = 1e-4 if name.endswith("trs.bias") else 1e-6       # analytically-zero gradient: Adam-normalised noise
+            np.testing.assert_allclose(res[True][2][name].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=atol, err_msg=name)
     finally:
         dist.destroy_process_group()
 
