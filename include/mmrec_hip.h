@@ -73,6 +73,15 @@ int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float
                        const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
                        float* partials, mmrec_stream_t stream);
 
+/* One LayerGCN layer in one launch (layergcn.py:131-135): y = A x ; w[row] = cosine_similarity(y[row], ego[row]) with
+ * eps 1e-8 per norm ; scaled = w * y (the next layer's input) ; acc_out = acc_in + scaled (acc_in NULL: acc_out = scaled;
+ * acc_out NULL: no sum).  Y (the unscaled product, needed by the backward) may be NULL.  d must be 64.  Plan arguments
+ * as in mmrec_spmm_csr_f32.  Results are bit-identical to mmrec_spmm_csr_f32 followed by mmrec_cos_scale_fwd_f32. */
+int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
+                                float* Y, const float* ego, float* scaled, float* w, const float* acc_in,
+                                float* acc_out, int32_t n_rows, int32_t d, int32_t long_row_threshold,
+                                const int32_t* long_rows, const int32_t* long_chunk_ptr, int32_t n_long,
+                                int32_t n_chunks, float* partials, mmrec_stream_t stream);
 /* Host-side plan helpers (pure CPU, rowptr is a HOST pointer).  count: returns n_long and n_chunks;
  * fill: writes long_rows[n_long] and long_chunk_ptr[n_long+1] (host arrays the caller copies to the
  * device).  partials workspace = n_chunks * 64 * 4 bytes. */

@@ -18,6 +18,7 @@ class GraphedTrainStep:
         self.static_batch = None
         self.static_loss = None
         self._warm = False
+        self.failed = False
 
     def invalidate(self):
         """Call when buffers the step reads were re-created (new epoch / rebuilt graph)."""
@@ -44,10 +45,19 @@ class GraphedTrainStep:
             # first use, which is not permitted while a stream is capturing
             self._warm = True
             return self._eager(batch)
+        if self.failed:
+            return self._eager(batch)
         if self.graph is None or batch.shape != self.static_batch.shape:
             if self.graph is not None and batch.shape != self.static_batch.shape:
                 return self._eager(batch)            # the short last batch of an epoch
-            self._capture(batch)
+            try:
+                self._capture(batch)
+            except Exception as ex:                  # something in this model's step cannot be captured: run eagerly
+                import logging
+                logging.getLogger().warning('hipGraph capture of the training step failed (%r); continuing eagerly' % (ex,))
+                self.failed, self.graph = True, None
+                torch.cuda.synchronize()
+                return self._eager(batch)
         else:
             self.static_batch.copy_(batch)
         self.opt.sync_lr()

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from mmrec_amd import _lib
+from mmrec_amd.utils.utils import graph_step_mode
 
 INT_MAX = 2 ** 31 - 1
 
@@ -150,7 +151,7 @@ def lazy_adam_enabled(config, n_elements=0):
     it from Sports (75 M: 1.90 -> 1.73 ms) and Clothing (3.36 -> 2.50 ms) up, 4.6 x at 500K items."""
     want = config['lazy_feature_adam']
     ok = (str(config['learner']).lower() == 'adam' and config['hip_fused_adam'] in (None, True) and
-          not config['hip_graph_step'] and not config['clip_grad_norm'] and    # clipping needs the dense .grad
+          graph_step_mode(config) != 'on' and not config['clip_grad_norm'] and    # clipping needs the dense .grad
           getattr(config['device'], 'type', str(config['device'])) == 'cuda')
     return (ok and n_elements >= AUTO_MIN_ELEMENTS) if want is None else (bool(want) and ok)
 

@@ -17,7 +17,7 @@ import torch.optim as optim
 from torch.nn.utils.clip_grad import clip_grad_norm_
 
 from mmrec_amd.utils.topk_evaluator import TopKEvaluator
-from mmrec_amd.utils.utils import dict2str, early_stopping
+from mmrec_amd.utils.utils import dict2str, early_stopping, graph_step_mode
 
 
 class AbstractTrainer(object):
@@ -79,7 +79,7 @@ class Trainer(AbstractTrainer):
         if name == 'adam' and on_gpu and (fused is None or fused):
             from mmrec_amd.common.optim import HipAdam   # one fused HIP kernel per tensor, same update rule
             return HipAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,
-                           capturable=bool(self.config['hip_graph_step']))
+                           capturable=self._graph_wanted())
         if any(getattr(p, '_lazy_table', None) is not None for p in self.model.parameters()):
             raise ValueError('the model was built with row-lazy feature tables (lazy_feature_adam) but this Trainer '
                              'does not use the fused HIP Adam: set lazy_feature_adam: False')
@@ -152,13 +152,20 @@ class Trainer(AbstractTrainer):
             return tuple(tuple_parts.cpu().tolist()), per_batch
         return sum(values), per_batch
 
+    def _graph_wanted(self):
+        """config `hip_graph_step`: 'on' = every model that does not opt out (`graph_capturable = False`); 'auto' (the
+        default) = only the plugins that declare `graph_capturable = True`; never with gradient clipping, the
+        Mirror-Gradient variant or on the CPU."""
+        mode = graph_step_mode(self.config)
+        flag = getattr(self.model, 'graph_capturable', None)
+        if mode == 'off' or self.mg or self.clip_grad_norm or not all(p.is_cuda for p in self.model.parameters()):
+            return False
+        return flag is not False if mode == 'on' else flag is True
+
     def _graphed_step(self, loss_func):
-        """hipGraph replay of the training step (config `hip_graph_step`): only for the plain single-loss
-        path with the capturable fused Adam, no gradient clipping, no Mirror-Gradient, and models that
-        do not change what a step does from batch to batch (`graph_capturable`, default True)."""
-        if not self.config['hip_graph_step'] or self.mg or self.clip_grad_norm:
-            return None
-        if not getattr(self.optimizer, 'capturable', False) or not getattr(self.model, 'graph_capturable', True):
+        """hipGraph replay of the training step: only for the plain single-loss path with the capturable fused Adam
+        (`_graph_wanted`) and models that do not change what a step does from batch to batch."""
+        if not self._graph_wanted() or not getattr(self.optimizer, 'capturable', False):
             return None
         if getattr(self, '_graphed', None) is None:
             from mmrec_amd.common.graph_step import GraphedTrainStep

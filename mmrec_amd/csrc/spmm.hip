@@ -55,10 +55,32 @@ struct RowEpilogue {
     const float* acc_in;
     float* acc_out;
     float alpha, beta, acc_scale;
+    // LayerGCN (d == 64 only): w = cos(y, ego row), scaled = w y, acc_out = acc_in + scaled (layergcn.py:131-135)
+    const float* ego;
+    float* scaled;
+    float* w_out;
 };
 
 template <int DCH>
 __device__ __forceinline__ void store_row(const RowEpilogue& ep, int row, int lane16, const float4 (&sum)[DCH]) {
+    if (DCH == 1 && ep.ego) {   // the 16 lanes of the group hold the whole 64-float row: the row statistics are 4 DPP steps
+        const size_t off = (size_t)row * 16 + lane16;
+        const float4 y = f4_scale(ep.alpha, sum[0]);
+        const float4 g = reinterpret_cast<const float4*>(ep.ego)[off];
+        // the arithmetic of cos_scale_fwd_kernel, instruction for instruction (bit-identical results)
+        const float dot = row16_sum(f4_dot(y, g));
+        const float ne = fmaxf(sqrtf(row16_sum(f4_dot(y, y))), 1e-8f);
+        const float ng = fmaxf(sqrtf(row16_sum(f4_dot(g, g))), 1e-8f);
+        const float w = dot / (ne * ng);
+        const float4 o = f4_scale(w, y);
+        if (ep.Y) st_y(reinterpret_cast<float4*>(ep.Y) + off, y);
+        st_y(reinterpret_cast<float4*>(ep.scaled) + off, o);
+        if (lane16 == 0) ep.w_out[row] = w;
+        if (ep.acc_out)
+            st_y(reinterpret_cast<float4*>(ep.acc_out) + off,
+                 ep.acc_in ? f4_add(reinterpret_cast<const float4*>(ep.acc_in)[off], o) : o);
+        return;
+    }
 #pragma unroll
     for (int ch = 0; ch < DCH; ++ch) {
         const size_t off = (size_t)row * (16 * DCH) + ch * 16 + lane16;  // float4 index
@@ -287,7 +309,7 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     if (n_long > 0 && (!long_rows || !long_chunk_ptr || !partials || n_chunks <= 0))
         return MMREC_ERR_BAD_ARG;
     if (Y == X) return MMREC_ERR_BAD_ARG;  // other rows still gather from X
-    RowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale};
+    RowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale, nullptr, nullptr, nullptr};
     hipStream_t s = mmrec_stream(stream);
     // small (cache-resident, latency-bound) graphs: one row per 16-lane group; large graphs: four
     const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
@@ -305,6 +327,32 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
         MMREC_SPMM_CASE(6)
     }
 #undef MMREC_SPMM_CASE
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+// One LayerGCN layer in ONE launch: y = A x, w = cos(y, ego) per row, scaled = w y, acc_out = acc_in + scaled
+// (layergcn.py:131-135; SURVEY.md 8b `spmm_csr_f32_layergcn`).  The cosine needs the finished row, which the group that
+// stores it holds in registers in all three places a row is finished (row blocks, single-chunk blocks, long-row reduce).
+extern "C" int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                                           const float* X, float* Y, const float* ego, float* scaled, float* w,
+                                           const float* acc_in, float* acc_out, int32_t n_rows, int32_t d,
+                                           int32_t long_row_threshold, const int32_t* long_rows,
+                                           const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
+                                           float* partials, mmrec_stream_t stream) {
+    if (d != MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    if (n_rows < 0 || n_long < 0 || n_chunks < 0 || long_row_threshold < 0) return MMREC_ERR_BAD_ARG;
+    if (n_rows == 0) return 0;
+    if (!rowptr || !X || !ego || !scaled || !w) return MMREC_ERR_BAD_ARG;
+    if (n_long > 0 && (!long_rows || !long_chunk_ptr || !partials || n_chunks <= 0)) return MMREC_ERR_BAD_ARG;
+    if (Y == X || scaled == X || acc_out == X) return MMREC_ERR_BAD_ARG;  // other rows still gather from X
+    RowEpilogue ep{nullptr, Y, acc_in, acc_out, 1.f, 0.f, 1.f, ego, scaled, w};
+    hipStream_t s = mmrec_stream(stream);
+    const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
+    const int blocks = (n_rows + 16 * rows_per_group - 1) / (16 * rows_per_group);
+    const int long_t = n_long > 0 ? long_row_threshold : INT32_MAX;
+    const int nch = n_long > 0 ? n_chunks : 0;
+    launch_spmm<1>(s, blocks, nch, rowptr, colidx, vals, X, ep, n_rows, long_t, rows_per_group, long_rows,
+                   long_chunk_ptr, n_long, partials);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

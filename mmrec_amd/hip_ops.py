@@ -265,19 +265,24 @@ class _LayerGCNSum(torch.autograd.Function):
         lib = _lib.load()
         E0 = E0.contiguous()
         L, n = int(n_layers), E0.shape[0]
-        acc = torch.zeros_like(E0)
+        if E0.shape[1] != EMB_DIM or E0.shape[0] != g.n_rows or g.n_cols != g.n_rows:
+            raise _lib.MMRecHipError("layergcn_sum needs E0 [n, %d] over a square graph of n rows" % EMB_DIM)
+        acc = torch.zeros_like(E0) if L == 0 else torch.empty_like(E0)
+        need_y = ctx.needs_input_grad[0]          # the unscaled products are only read by the backward
         ys, ws = [], []
         cur = E0
-        for _ in range(L):
-            y = torch.empty_like(E0)
-            spmm_raw(g, cur, Y=y)
+        for layer in range(L):                    # SpMM + cosine re-weighting + layer sum: ONE launch per layer
+            y = torch.empty_like(E0) if need_y else None
             out, w = torch.empty_like(E0), torch.empty(n, dtype=torch.float32, device=E0.device)
-            _lib.check(lib.mmrec_cos_scale_fwd_f32(_p(y), _p(E0), _p(out), _p(w), _p(acc), n, EMB_DIM,
-                                                   _stream()), "cos_scale_fwd")
+            _lib.check(lib.mmrec_spmm_csr_f32_layergcn(
+                _p(g.rowptr), _p(g.colidx), _p(g.vals), _p(cur), _p(y), _p(E0), _p(out), _p(w),
+                _p(acc) if layer > 0 else None, _p(acc), g.n_rows, EMB_DIM, g.long_row_threshold, _p(g.long_rows),
+                _p(g.long_chunk_ptr), g.n_long, g.n_chunks, _p(g.partials_for(EMB_DIM)), _stream()), "spmm_layergcn")
             ys.append(y), ws.append(w)
             cur = out
         ctx.g, ctx.L = g, L
-        ctx.save_for_backward(E0, *ys, *ws)
+        if need_y:
+            ctx.save_for_backward(E0, *ys, *ws)
         return acc
 
     @staticmethod

@@ -12,6 +12,8 @@ from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender, emb_loss_
 
 
 class BPR(FusedEvalMixin, GeneralRecommender):
+    graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
         self.embedding_size = config['embedding_size']

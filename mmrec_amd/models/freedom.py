@@ -55,6 +55,8 @@ def load_or_build_mm_adj(config, v_feat, t_feat, knn_k, mm_image_weight, n_items
 
 
 class FREEDOM(FusedEvalMixin, GeneralRecommender):
+    graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
         self.embedding_dim = config['embedding_size']

@@ -19,6 +19,8 @@ from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
 
 
 class LayerGCN(FusedEvalMixin, GeneralRecommender):
+    graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)

@@ -13,6 +13,8 @@ from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender, emb_loss_
 
 
 class VBPR(FusedEvalMixin, GeneralRecommender):
+    graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
     def __init__(self, config, dataloader):
         super().__init__(config, dataloader)
         self.u_embedding_size = self.i_embedding_size = config['embedding_size']

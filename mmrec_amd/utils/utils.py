@@ -81,6 +81,16 @@ def random_sample_range(n, k):
     return out
 
 
+def graph_step_mode(config):
+    """`hip_graph_step`: True / False, or absent / 'auto' = replay the training step as a hipGraph for the plugins that
+    declare `graph_capturable = True` (verified: same kernels in the same order, tests/test_models_gpu.py) and run every
+    other model -- anything a user drops in -- eagerly."""
+    v = config['hip_graph_step']
+    if v is None or str(v).lower() == 'auto':
+        return 'auto'
+    return 'on' if v is True or str(v).lower() in ('true', '1', 'yes', 'on') else 'off'
+
+
 def eval_batch_size(config):
     """Batch size of the evaluation loaders.  The reference's 4096 (overall.yaml: eval_batch_size) exists because
     `full_sort_predict` materialises a [batch, n_items] score matrix; the fused score + mask + top-K never does, and

@@ -1,0 +1,135 @@
+"""GPU: north_star's accuracy target -- "Recall@20 within 1e-4 of reference on Amazon-Baby" -- on TRAINED models.
+
+One full training epoch at Amazon-Baby shape (19,445 users x 7,050 items, 58 optimizer steps of 2048 triplets from the
+loader, whose batches are the reference's bit for bit: tests/test_plumbing_golden.py) through the plugin + Trainer on the
+HIP kernels (fused Adam included), against the SAME epoch run by the CPU oracle with torch.optim.Adam -- the reference's
+training loop restated (trainer.py:130-194: zero_grad, calculate_loss, backward, step per batch) -- with the device RNG
+draws injected (the kept edges of the epoch's pruned graph).  Then the reference's evaluation (trainer.py:292-311 +
+topk_evaluator.py:58-102) on both: the epoch's loss within 1e-4 relative, Recall@20 / NDCG@20 (and every other metric of
+the dict) within 1e-4, final embeddings within 1e-4 of their scale.
+
+The Amazon datasets are not shipped with the reference (data/README.md); the graph is synthetic of that shape."""
+import numpy as np
+import pytest
+import torch
+
+import tests.test_config_shapes_gpu as S
+from oracle import mmrec_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_epoch(params, names, loss_fn, batches, lr):
+    """trainer.py:130-194 on the CPU: one Adam over the model's parameters in registration order"""
+    opt = torch.optim.Adam([params[n] for n in names], lr=lr)
+    total = 0.0
+    for b in batches:
+        opt.zero_grad()
+        loss = loss_fn(b)
+        loss.backward()
+        opt.step()
+        total += float(loss.detach())
+    return total
+
+
+def _metrics(topk_idx, valid_data):
+    pos_len = np.asarray(valid_data.get_eval_len_list())
+    pos_flat = np.concatenate([np.asarray(p) for p in valid_data.get_eval_items()])
+    return orc.topk_metrics(orc.hit_matrix(topk_idx, pos_flat, pos_len), pos_len)
+
+
+def _oracle_eval(u_all, i_all, valid_data):
+    """trainer.py:292-311 with the oracle's pieces, batch by batch of 4096 users"""
+    out = []
+    for batch in valid_data:
+        users, mask = batch[0].cpu().numpy(), batch[1].cpu().numpy()
+        for a in range(0, users.shape[0], 4096):
+            b = min(a + 4096, users.shape[0])
+            sel = (mask[0] >= a) & (mask[0] < b)
+            scores = orc.full_sort_scores(u_all, i_all, users[a:b])
+            out.append(orc.mask_topk(scores, np.stack([mask[0][sel] - a, mask[1][sel]]), 50)[1].numpy())
+    return np.concatenate(out)
+
+
+def _run(tmp_path, model_name, hyper, oracle_loss, oracle_forward, drop):
+    from mmrec_amd.common.trainer import Trainer
+    dev = torch.device("cuda:0")
+    config, train_data, valid_data, model = S.build_shape(tmp_path, model_name, "baby", hyper)
+    nu, ni = model.n_users, model.n_items
+    n = nu + ni
+    keep_len = int(model.edge_values.numel() * (1.0 - drop))
+    keep = torch.multinomial(model.edge_values.detach().cpu(), keep_len, generator=torch.Generator().manual_seed(7))
+    model.set_kept_edges(keep.to(dev))
+    batches = [b.clone() for b in train_data]                      # the epoch's batches, as the loader yields them
+    assert len(batches) >= 50 and batches[0].shape == (3, 2048)
+    params = S.cpu_leaves(model)                                    # BEFORE training
+    names = [nm for nm, _ in model.named_parameters()]
+    # device: the plugin through the Trainer (fused Adam, per-epoch loss readback)
+    trainer = Trainer(config, model)
+    loss_dev, _ = trainer._train_epoch(batches, 0)
+    dev_metrics = trainer.evaluate(valid_data)
+    # oracle: same initial parameters, same batches, same kept edges
+    a_idx, a_val = orc.masked_adj_coo(model.edge_indices.cpu().numpy(), keep.numpy(), nu, ni)
+    masked = orc.sparse_coo(a_idx, a_val, n)
+    cpu_batches = [b.cpu().numpy() for b in batches]
+    loss_ref = _oracle_epoch(params, names, lambda b: oracle_loss(params, masked, b), cpu_batches, config["learning_rate"])
+    np.testing.assert_allclose(loss_dev, loss_ref, rtol=1e-4)
+    trained = dict(model.named_parameters())
+    for nm in names:
+        if nm.endswith("trs.bias"):
+            continue                                                # analytically-zero gradient: Adam-normalised rounding noise
+        ref = params[nm].detach()
+        d = (trained[nm].detach().cpu() - ref).abs().max().item()
+        assert d <= 1e-4 * ref.abs().max().item(), (nm, d)
+    full = orc.sparse_coo(*[x for x in _norm_adj_of(model)], n)
+    with torch.no_grad():
+        u_ref, i_ref = oracle_forward({k: v.detach() for k, v in params.items()}, full)
+    ref_metrics = _metrics(_oracle_eval(u_ref, i_ref, valid_data), valid_data)
+    for k, v in ref_metrics.items():
+        assert abs(dev_metrics[k] - v) <= 1e-4 + 1e-12, (k, dev_metrics[k], v)
+    return loss_dev, loss_ref, dev_metrics, ref_metrics
+
+
+def _norm_adj_of(model):
+    g = model.norm_adj_matrix if hasattr(model, "norm_adj_matrix") else model.norm_adj
+    return g.to_coo_host()
+
+
+def test_layergcn_trained_epoch_at_baby_shape(tmp_path):
+    """BASELINE config 2: LayerGCN, 4 layers, edge dropout 0.1 (layergcn.py:51-70 draw injected), reg 1e-3."""
+    def loss(p, adj, b):
+        return orc.layergcn_loss(adj, p["user_embeddings"], p["item_embeddings"], 4, b, 1e-3)
+
+    def fwd(p, adj):
+        return orc.layergcn_forward(adj, p["user_embeddings"], p["item_embeddings"], 4)
+    out = _run(tmp_path, "LayerGCN", {"n_layers": 4, "dropout": 0.1, "reg_weight": 1e-3}, loss, fwd, 0.1)
+    print("LayerGCN/baby: epoch loss device %.6f oracle %.6f; recall@20 %.4f / %.4f" %
+          (out[0], out[1], out[2]["recall@20"], out[3]["recall@20"]))
+
+
+def test_freedom_trained_epoch_at_baby_shape(tmp_path):
+    """FREEDOM at Baby shape (n_ui 2, n_mm 1, dropout 0.8: freedom.py:128-143 draw injected; the frozen item-item graph
+    is the plugin's own, shared with the oracle as its cache file would be), the plugin's default gathered-rows
+    projection and the dense fused Adam over the 7,050 x 4096 / 384 feature tables."""
+    holder = {}
+
+    def loss(p, adj, b):
+        return orc.freedom_loss(adj, holder["mm"], p["user_embedding.weight"], p["item_id_embedding.weight"],
+                                p["image_embedding.weight"], p["image_trs.weight"], p["image_trs.bias"],
+                                p["text_embedding.weight"], p["text_trs.weight"], p["text_trs.bias"], 2, 1, b, 1e-3)
+
+    def fwd(p, adj):
+        return orc.freedom_forward(adj, holder["mm"], p["user_embedding.weight"], p["item_id_embedding.weight"], 2, 1)
+    import mmrec_amd.models.freedom as fm
+    real_init = fm.FREEDOM.__init__
+
+    def init_and_share(self, config, dataset):
+        real_init(self, config, dataset)
+        holder["mm"] = orc.sparse_coo(*self.mm_adj.to_coo_host(), self.n_items, self.n_items)
+    fm.FREEDOM.__init__ = init_and_share
+    try:
+        out = _run(tmp_path, "FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3, "lazy_feature_adam": False}, loss, fwd, 0.8)
+    finally:
+        fm.FREEDOM.__init__ = real_init
+    print("FREEDOM/baby: epoch loss device %.6f oracle %.6f; recall@20 %.4f / %.4f" %
+          (out[0], out[1], out[2]["recall@20"], out[3]["recall@20"]))
