@@ -19,7 +19,9 @@
 
 // tools/spmm_lab.py builds this file with a cache-policy mask (the library only ever uses MMREC_SPMM_POLICY below):
 // bit0 colidx / vals streamed with nontemporal loads, bit1 Y / acc written with nontemporal stores, bit2 X rows gathered
-// with nontemporal loads
+// with nontemporal loads.  (Measured, profiles/r02_spmm_cache_policy_lab.log: bits 0 / 1 change nothing, bit 2 costs 50 %;
+// a per-column hot / cold split -- nontemporal gathers for unpopular columns only -- cost 60 %:
+// profiles/r02_spmm_lab_hot_cold_nontemporal.log.)
 #ifndef MMREC_SPMM_LAB
 #define MMREC_SPMM_LAB 0
 #endif
