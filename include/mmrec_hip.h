@@ -315,9 +315,12 @@ int mmrec_cosine_bwd_f32(const float* X, const int64_t* ix, const float* Y, cons
  *   owner    [n_rows] int32, INT_MAX where idle: mmrec_adam_rows_owner marks the first position of every row in `ids`
  *            (duplicates allowed); catchup / step consume the marks (entries are INT_MAX again afterwards)
  *   catchup: bring the rows of `ids` (ids == NULL: all n_rows rows) to step t_now
- *   step:    optimizer step t (= t_now + 1) on the rows of `ids`; g [n_ids][F]: row i holds the SUMMED gradient of the
- *            table row whose first occurrence is position i (other positions are ignored)
+ *   step:    optimizer step t (= t_now + 1) on the rows of `ids`; g [n_ids][F]: row i holds the gradient of OCCURRENCE i;
+ *            the occurrences of a table row are summed in position order by the workgroup of its first occurrence
+ *            (n_ids <= MMREC_ADAM_ROWS_MAX_IDS: the position list lives in LDS).  presummed != 0: row i already holds the
+ *            SUMMED gradient of the table row whose first occurrence is position i (other positions are ignored)
  * replaces: torch.optim.Adam.step on image_embedding / text_embedding (freedom.py:58,61; trainer.py:111-128,189). */
+#define MMREC_ADAM_ROWS_MAX_IDS 16000
 int mmrec_adam_hist_set(float* hist, int32_t t, float lr, float beta1, float beta2, mmrec_stream_t stream);
 int mmrec_adam_rows_owner(const int64_t* ids, int32_t n, int32_t* owner, mmrec_stream_t stream);
 int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, int32_t n_ids,
@@ -325,7 +328,7 @@ int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const int64_t* ids
                                 float beta1, float beta2, float eps, float weight_decay, mmrec_stream_t stream);
 int mmrec_adam_rows_step_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, const float* g,
                              int32_t n_ids, int32_t F, int32_t* last_step, int32_t t, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, mmrec_stream_t stream);
+                             float beta2, float eps, float weight_decay, int32_t presummed, mmrec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -75,7 +75,7 @@ SIGNATURES = {
     "mmrec_adam_rows_catchup_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, c_float,
                                               c_float, c_float, c_float, _P]),
     "mmrec_adam_rows_step_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, c_float, c_float,
-                                           c_float, c_float, c_float, _P]),
+                                           c_float, c_float, c_float, c_int32, _P]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ from mmrec_amd import _lib
 from mmrec_amd.utils.utils import graph_step_mode
 
 INT_MAX = 2 ** 31 - 1
+MAX_IDS = 16000           # MMREC_ADAM_ROWS_MAX_IDS (include/mmrec_hip.h)
 
 
 def _p(t):
@@ -131,11 +132,14 @@ class LazyRowEmbedding(nn.Embedding):
             self._hist = grown
         _lib.check(lib.mmrec_adam_hist_set(_p(self._hist), self._t, float(lr), b1, b2, _stream()), "adam_hist_set")
         _lib.check(lib.mmrec_adam_rows_owner(_p(ids), n, _p(self._owner), _stream()), "adam_rows_owner")
-        # rows used through several calls of this step were caught up by the first one; summed gradient of a row
-        # -> the slot of its first occurrence
-        g = torch.zeros_like(dY).index_add_(0, self._owner.index_select(0, ids).long(), dY)
+        # rows used through several calls of this step were caught up by the first one.  The workgroup of a row's first
+        # occurrence sums the row's occurrences itself, in position order (deterministic; no zero-fill + index_add_ pass
+        # over the [n, F] gradient); id lists too long for its LDS position list are pre-summed into the owner slots
+        presummed = n > MAX_IDS
+        g = torch.zeros_like(dY).index_add_(0, self._owner.index_select(0, ids).long(), dY) if presummed else dY
         _lib.check(lib.mmrec_adam_rows_step_f32(_p(w), _p(m), _p(v), _p(ids), _p(self._owner), _p(g), n, w.shape[1],
-                                                _p(self._last_step), self._t, float(lr), b1, b2, eps, wd, _stream()),
+                                                _p(self._last_step), self._t, float(lr), b1, b2, eps, wd, int(presummed),
+                                                _stream()),
                    "adam_rows_step")          # (owner marks consumed by the kernel)
         return True
 

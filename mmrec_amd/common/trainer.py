@@ -59,12 +59,12 @@ class Trainer(AbstractTrainer):
         self.best_valid_result = zeros
         self.best_test_upon_valid = zeros
         self.train_loss_dict = dict()
+        self.mg = mg
         self.optimizer = self._build_optimizer()
         base, period = config['learning_rate_scheduler']
         self.lr_scheduler = optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda=lambda ep: base ** (ep / period))
         self.eval_type = config['eval_type']
         self.evaluator = TopKEvaluator(config)
-        self.mg = mg
         self.alpha1, self.alpha2, self.beta = config['alpha1'], config['alpha2'], config['beta']
         fused = config['hip_fused_eval']
         self.fused_eval = True if fused is None else bool(fused)

@@ -244,23 +244,49 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
     if (threadIdx.x == 0) last_step[row] = t_now;
 }
 
-// Optimizer step t on the listed rows (all caught up to t - 1): g[i] = summed gradient of the row first seen at
-// position i of the id list (rows of other positions are ignored).
+// Optimizer step t on the listed rows (all caught up to t - 1).  g[i] = gradient of OCCURRENCE i of the id list; the
+// workgroup of a row's first occurrence (its owner) sums the row's occurrences itself, in position order: it scans the
+// id list once (n ids from L2; duplicates are rare) into an LDS position list, then adds the gradient rows while the
+// parameter row is in registers.  Deterministic (the former zero-fill + index_add_ pre-pass summed with float atomics)
+// and two passes over the [n, F] gradient cheaper.  Dynamic LDS: n ints.
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(
     float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const int64_t* __restrict__ ids,
-    int* __restrict__ owner, const float* __restrict__ g, int F, int* __restrict__ last_step, int t, AdamArgs a) {
+    int* __restrict__ owner, const float* __restrict__ g, int n, int F, int* __restrict__ last_step, int t, AdamArgs a) {
+    // n == 0: g is already summed per owner slot (id lists too long for the LDS position list): only the own position
+    extern __shared__ int s_pos[];
+    __shared__ int s_wave[4];
+    __shared__ int s_total;
     const int64_t row = ids[blockIdx.x];
     if (owner[row] != (int)blockIdx.x) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_total = 0;
     __syncthreads();
     if (threadIdx.x == 0) owner[row] = INT_MAX;         // idle again
+    for (int base = 0; base < n; base += 256) {         // ascending positions, compacted in order
+        const int i = base + threadIdx.x;
+        const bool hit = i < n && ids[i] == row;
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_total;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (hit) s_pos[off + __popcll(b & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) s_total += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (n == 0 && threadIdx.x == 0) { s_pos[0] = blockIdx.x; s_total = 1; }
+    __syncthreads();
+    const int cnt = s_total;
     const int f4 = F / 4;
     float4* p4 = reinterpret_cast<float4*>(p + (size_t)row * F);
     float4* m4 = reinterpret_cast<float4*>(m + (size_t)row * F);
     float4* v4 = reinterpret_cast<float4*>(v + (size_t)row * F);
-    const float4* g4 = reinterpret_cast<const float4*>(g + (size_t)blockIdx.x * F);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
     for (int c = threadIdx.x; c < f4; c += 256) {
         float4 pp = p4[c], mm = m4[c], vv = v4[c];
-        const float4 gg = g4[c];
+        float4 gg = g4[(size_t)s_pos[0] * f4 + c];      // s_pos[0] == blockIdx.x
+        for (int q = 1; q < cnt; ++q) gg = f4_add(gg, g4[(size_t)s_pos[q] * f4 + c]);
         adam_one(pp.x, gg.x, mm.x, vv.x, a);
         adam_one(pp.y, gg.y, mm.y, vv.y, a);
         adam_one(pp.z, gg.z, mm.z, vv.z, a);
@@ -303,14 +329,15 @@ extern "C" int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const i
 extern "C" int mmrec_adam_rows_step_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
                                         const float* g, int32_t n_ids, int32_t F, int32_t* last_step, int32_t t,
                                         float lr, float beta1, float beta2, float eps, float weight_decay,
-                                        mmrec_stream_t stream) {
+                                        int32_t presummed, mmrec_stream_t stream) {
     if (F <= 0 || (F & 3) || t < 1 || n_ids < 0) return MMREC_ERR_BAD_ARG;
     if (n_ids == 0) return 0;
     if (!p || !m || !v || !ids || !owner || !g || !last_step) return MMREC_ERR_BAD_ARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     const AdamArgs a{(float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2))};
-    hipLaunchKernelGGL(adam_rows_step_kernel, dim3(n_ids), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner, g, F,
-                       last_step, t, a);
+    if (!presummed && n_ids > MMREC_ADAM_ROWS_MAX_IDS) return MMREC_ERR_UNSUPPORTED;     // the position list lives in LDS
+    hipLaunchKernelGGL(adam_rows_step_kernel, dim3(n_ids), dim3(256), presummed ? sizeof(int) : (size_t)n_ids * sizeof(int),
+                       mmrec_stream(stream), p, m, v, ids, owner, g, presummed ? 0 : n_ids, F, last_step, t, a);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

@@ -782,11 +782,14 @@ def test_lazy_row_adam_equals_dense(dev):
         sch_d = torch.optim.lr_scheduler.LambdaLR(opt_d, lr_lambda=lambda ep: 0.8 ** ep)
         sch_l = torch.optim.lr_scheduler.LambdaLR(opt_l, lr_lambda=lambda ep: 0.8 ** ep)
         for step in range(12):
-            ids = torch.randint(0, 60 if step % 3 else n, (37,), generator=g)       # rows >= 60 are touched rarely
+            # step 10: an id list longer than MMREC_ADAM_ROWS_MAX_IDS (the owner workgroups' LDS position list): the
+            # pre-summed fallback; every other step: the owners sum their duplicates themselves, in position order
+            n_ids = 16500 if step == 10 else 37
+            ids = torch.randint(0, 60 if step % 3 else n, (n_ids,), generator=g)       # rows >= 60 are touched rarely
             ids2 = torch.cat([ids[:5], torch.randint(0, n, (6,), generator=g)])        # second use in the same step
-            # gradients on a coarse dyadic grid: a row's duplicates are summed by atomics in both paths, and only
-            # exactly representable partial sums make that order-free (the test is about the optimizer, not about atomics)
-            coef = (torch.randint(-16, 17, (37, F), generator=g).float() / 16).to(dev)
+            # gradients on a coarse dyadic grid: a row's duplicates are summed in another order by the dense path's
+            # atomics, and only exactly representable partial sums make that order-free (the test is about the optimizer)
+            coef = (torch.randint(-16, 17, (n_ids, F), generator=g).float() / (16 if n_ids == 37 else 1024)).to(dev)
             coef2 = (torch.randint(-16, 17, (11, F), generator=g).float() / 16).to(dev)
             ids, ids2 = ids.to(dev), ids2.to(dev)
             rows_l, rows_l2 = lazy.rows(ids), lazy.rows(ids2)

@@ -53,7 +53,8 @@ def main():
     ap.add_argument("config", choices=sorted(CONFIGS))
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--device-neg-sampling", action="store_true")
-    ap.add_argument("--graph-step", action="store_true", help="replay the training step as a hipGraph")
+    ap.add_argument("--graph-step", action="store_true", help="replay the training step as a hipGraph (every model that does not opt out)")
+    ap.add_argument("--eager", action="store_true", help="never replay (default: the plugins that declare graph_capturable)")
     ap.add_argument("--dense-adam", action="store_true", help="force the dense fused Adam on the trainable feature tables "
                                                                "(FREEDOM, BM3 default to the row-lazy exact Adam)")
     args = ap.parse_args()
@@ -77,8 +78,9 @@ def main():
     from mmrec_amd.utils.dataset import RecDataset
     from mmrec_amd.utils.utils import eval_batch_size, get_model, init_seed
     cd = dict(hyper, gpu_id=0, use_gpu=True, data_path=root + "/", epochs=args.epochs,
-              save_recommended_topk=False, device_neg_sampling=args.device_neg_sampling,
-              hip_graph_step=args.graph_step)
+              save_recommended_topk=False, device_neg_sampling=args.device_neg_sampling)
+    if args.graph_step or args.eager:
+        cd['hip_graph_step'] = bool(args.graph_step)       # default: 'auto' (overall.yaml)
     if args.dense_adam:
         cd['lazy_feature_adam'] = False
     config = Config(model_name, ds, cd)
