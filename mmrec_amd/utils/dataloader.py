@@ -77,7 +77,17 @@ class TrainDataLoader(AbstractDataLoader):
             self.sample_func = self._user_ids_only
         else:
             self.sample_func = self._pairs_with_negative
-        self.history_items_per_u = {u: set(g.values) for u, g in dataset.df.groupby(uid)[iid]}
+        # per-user training history: the reference keeps {user: set(items)} (dataloader.py:282-291, one groupby group per
+        # user: ~20 s at 1M users); here the same sets live as a CSR (sorted unique items per user) built by one sort, and
+        # the dict the reference's attribute name promises is materialised only if somebody asks for it
+        u_arr, i_arr = dataset.df[uid].values.astype(np.int64), dataset.df[iid].values.astype(np.int64)
+        stride = np.int64(i_arr.max() + 1) if i_arr.size else np.int64(1)
+        key = np.unique(u_arr * stride + i_arr)
+        n_users = int(dataset.user_num)
+        self._hist_rowptr = np.zeros(n_users + 1, dtype=np.int64)
+        np.cumsum(np.bincount(key // stride, minlength=n_users), out=self._hist_rowptr[1:])
+        self._hist_items = (key % stride).astype(np.int64) if key.size else np.zeros(1, np.int64)
+        self._history_dict = None
         self.neighborhood_loss_required = config['use_neighborhood_loss']
         if self.neighborhood_loss_required:
             raise NotImplementedError('use_neighborhood_loss is not on the accelerated path')
@@ -88,6 +98,13 @@ class TrainDataLoader(AbstractDataLoader):
         self._native_sampler = None      # resolved on first use: C host sampler of the library, or False
         self._cols_of = self._cols = None
         self._items_arr = None
+
+    @property
+    def history_items_per_u(self):
+        if self._history_dict is None:
+            rp, it = self._hist_rowptr, self._hist_items
+            self._history_dict = {u: set(it[rp[u]:rp[u + 1]].tolist()) for u in range(len(rp) - 1) if rp[u + 1] > rp[u]}
+        return self._history_dict
 
     def pretrain_setup(self):
         """Called once per hyper-parameter combination after seeding: restores the unshuffled data and
@@ -145,9 +162,8 @@ class TrainDataLoader(AbstractDataLoader):
     def _device_negatives(self, users_dev):
         from mmrec_amd import hip_ops
         if self._dev_sampler is None:
-            n_users = self.dataset.user_num
-            hist = [np.fromiter(self.history_items_per_u.get(u, ()), dtype=np.int64) for u in range(n_users)]
-            rowptr, col = hip_ops.lists_to_csr(hist, self.device)
+            rowptr = torch.from_numpy(self._hist_rowptr.astype(np.int32)).to(self.device)    # items sorted per user
+            col = torch.from_numpy(self._hist_items.astype(np.int32)).to(self.device)
             cand = torch.tensor(sorted(self.all_items_set), dtype=torch.int32, device=self.device)
             self._dev_sampler = (rowptr, col, cand)
         rowptr, col, cand = self._dev_sampler
@@ -180,13 +196,6 @@ class TrainDataLoader(AbstractDataLoader):
             try:
                 from mmrec_amd import _lib
                 self._native_sampler = _lib.load().mmrec_host_sample_negatives
-                n_users = self.dataset_bk.user_num
-                hist = [np.sort(np.fromiter(self.history_items_per_u.get(u, ()), dtype=np.int64)) for u in range(n_users)]
-                self._hist_rowptr = np.zeros(n_users + 1, dtype=np.int64)
-                np.cumsum([len(h) for h in hist], out=self._hist_rowptr[1:])
-                self._hist_items = np.concatenate(hist) if n_users else np.zeros(0, np.int64)
-                if self._hist_items.size == 0:
-                    self._hist_items = np.zeros(1, np.int64)
             except Exception:        # host-only use without the built library (CPU plumbing runs)
                 self._native_sampler = False
         if self._native_sampler is False or self.all_item_len.bit_length() > 32:
@@ -245,18 +254,35 @@ class EvalDataLoader(AbstractDataLoader):
             raise ValueError('Training datasets is nan')
         uid, iid = dataset.uid_field, dataset.iid_field
         eval_u = dataset.df[uid].unique()
-        train_groups = additional_dataset.df.groupby(additional_dataset.uid_field)[additional_dataset.iid_field]
-        train_lists = [train_groups.get_group(u).values for u in eval_u]
-        self.train_pos_len_list = [len(x) for x in train_lists]
-        rows = np.repeat(np.arange(len(eval_u), dtype=np.int64), self.train_pos_len_list)
-        cols = np.concatenate(train_lists).astype(np.int64) if train_lists else np.zeros(0, np.int64)
-        self.pos_items_per_u = torch.from_numpy(np.stack([rows, cols])).to(self.device)
-        self._mask_offsets = np.concatenate([[0], np.cumsum(self.train_pos_len_list)])
-        eval_groups = dataset.df.groupby(uid)[iid]
-        self.eval_items_per_u = [eval_groups.get_group(u).values for u in eval_u]
-        self.eval_len_list = np.asarray([len(x) for x in self.eval_items_per_u])
+        # the reference walks `groupby(...).get_group(u)` user by user (dataloader.py:359-407: 2 x 50 us per user, minutes
+        # at 1M users); the same lists -- a user's items in frame order, users in order of first appearance -- come
+        # out of one stable sort per frame
+        train_flat, train_len = self._lists_in_user_order(additional_dataset.df[additional_dataset.uid_field].values,
+                                                         additional_dataset.df[additional_dataset.iid_field].values, eval_u)
+        if train_len.size and train_len.min() == 0:        # get_group raises for a user without training interactions
+            raise KeyError(eval_u[int(np.argmin(train_len))])
+        self.train_pos_len_list = train_len.tolist()
+        rows = np.repeat(np.arange(len(eval_u), dtype=np.int64), train_len)
+        self.pos_items_per_u = torch.from_numpy(np.stack([rows, train_flat.astype(np.int64)])).to(self.device)
+        self._mask_offsets = np.concatenate([[0], np.cumsum(train_len)])
+        eval_flat, eval_len = self._lists_in_user_order(dataset.df[uid].values, dataset.df[iid].values, eval_u)
+        self.eval_items_per_u = np.split(eval_flat, np.cumsum(eval_len)[:-1]) if len(eval_u) else []
+        self.eval_len_list = np.asarray(eval_len)
         self.eval_u = torch.tensor(eval_u).type(torch.LongTensor).to(self.device)
         self._batch_cache = {}
+
+    @staticmethod
+    def _lists_in_user_order(uids, iids, users):
+        """-> (items of users[0] ++ items of users[1] ++ ..., lengths): each user's items in their order in the frame"""
+        uids, iids = np.asarray(uids), np.asarray(iids)
+        order = np.argsort(uids, kind='stable')
+        su, si = uids[order], iids[order]
+        lo, hi = np.searchsorted(su, users, 'left'), np.searchsorted(su, users, 'right')
+        lens = (hi - lo).astype(np.int64)
+        total = int(lens.sum())
+        starts = np.cumsum(lens) - lens
+        idx = np.repeat(lo - starts, lens) + np.arange(total, dtype=np.int64)
+        return si[idx], lens
 
     @property
     def pr_end(self):

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 THROUGH THE PLUGIN API on one MI355X: the synthetic 1M-user / 500K-item / 10M-interaction dataset
+(mmrec_amd/synth.py, reference on-disk format, 8.2 GB image + 0.77 GB text features) -> Config -> RecDataset -> loaders ->
+FREEDOM / ShardedFREEDOM -> Trainer steps -> evaluation.
+
+    python tools/run_c5_plugin.py            # plain FREEDOM, then ShardedFREEDOM (n_gpus code path, single-rank RCCL group,
+                                             # collectives forced): ms per training step, evaluation users/s, same losses
+
+The sharded run exercises on the device, at full size, what world-size 2 / 3 runs are tested for on the CPU (gloo): the
+nnz-balanced chunked row sharding, the all-gather per layer forward and backward, the item-sharded feature tables with
+the row-lazy Adam, the owner-computed projection exchange and the sharded evaluation."""
+import os
+import socket
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmrec_amd import synth  # noqa: E402
+
+
+def log(*a):
+    print("[c5]", *a, flush=True)
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    root = os.environ.get("MMREC_C5_ROOT") or tempfile.mkdtemp(prefix="mmrec_c5_", dir="/tmp")
+    t0 = time.time()
+    if not os.path.exists(os.path.join(root, "c5", "image_feat.npy")):
+        nu, ni, ne = synth.write_dataset(root, "c5", seed=0)
+        log("dataset written: %d users, %d items, %d interactions (%.0fs)" % (nu, ni, ne, time.time() - t0))
+    from mmrec_amd.common.trainer import Trainer
+    from mmrec_amd.utils.configurator import Config
+    from mmrec_amd.utils.dataloader import EvalDataLoader, TrainDataLoader
+    from mmrec_amd.utils.dataset import RecDataset
+    from mmrec_amd.utils.utils import eval_batch_size, get_model, init_seed
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    losses = {}
+    for sharded in (False, True):
+        cd = dict(gpu_id=0, use_gpu=True, data_path=root + "/", epochs=1, save_recommended_topk=False, dropout=0.8,
+                  reg_weight=1e-3, dist_force_collectives=True)
+        config = Config("FREEDOM", "c5", cd)
+        for k, v in cd.items():
+            config[k] = v
+        config["seed"] = 999
+        t = time.time()
+        data = RecDataset(config)
+        str(data)
+        tr, va, te = data.split()
+        str(tr), str(va), str(te)
+        train_data = TrainDataLoader(config, tr, batch_size=config["train_batch_size"], shuffle=True)
+        valid_data = EvalDataLoader(config, va, additional_dataset=tr, batch_size=eval_batch_size(config))
+        init_seed(999)
+        train_data.pretrain_setup()
+        log("sharded=%s: dataset + loaders %.1fs" % (sharded, time.time() - t))
+        if sharded and not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=config["device"])
+        t = time.time()
+        model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(config["device"])
+        torch.cuda.synchronize()
+        log("sharded=%s: model built in %.1fs (%d parameters; kNN graph cached after the first build)" %
+            (sharded, time.time() - t, sum(p.numel() for p in model.parameters())))
+        trainer = Trainer(config, model)
+        t = time.time()
+        keep = torch.multinomial(model.edge_values, int(model.edge_values.numel() * 0.2),
+                                 generator=torch.Generator(device=model.edge_values.device).manual_seed(5))
+        model.set_kept_edges(keep)
+        torch.cuda.synchronize()
+        log("sharded=%s: pruned graph rebuilt in %.2fs" % (sharded, time.time() - t))
+        batches = []
+        for b in train_data:
+            batches.append(b)
+            if len(batches) == steps + 3:
+                break
+        trainer._train_epoch(batches[:3], 0)                        # warm-up
+        torch.cuda.synchronize()
+        t = time.time()
+        total, per = trainer._train_epoch(batches[3:], 0)
+        torch.cuda.synchronize()
+        dt = time.time() - t
+        losses[sharded] = [float(x) for x in per]
+        log("sharded=%s: %d training steps, %.2f ms/step (loss first %.6f last %.6f)" %
+            (sharded, steps, dt / steps * 1e3, losses[sharded][0], losses[sharded][-1]))
+        t = time.time()
+        res = trainer.evaluate(valid_data)
+        torch.cuda.synchronize()
+        dt = time.time() - t
+        log("sharded=%s: evaluation of %d users in %.2fs (%.0f users/s incl. metrics), recall@20 %.4f" %
+            (sharded, valid_data.pr_end, dt, valid_data.pr_end / dt, res["recall@20"]))
+        log("sharded=%s: peak device memory %.1f GB" % (sharded, torch.cuda.max_memory_allocated() / 2 ** 30))
+        del model, trainer, train_data, valid_data, data
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+    a, b = np.array(losses[False]), np.array(losses[True])
+    log("max relative loss difference sharded vs plain over %d steps: %.2e" % (steps, np.abs(a / b - 1).max()))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
