@@ -389,6 +389,9 @@ def measure_traffic(g, n_nodes):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        log("bench.py is itself running under a profiler: not nesting rocprofv3 (quoting the committed profile)")
+        return None
     tmp = tempfile.mkdtemp(prefix="mmrec_pmc_", dir="/tmp")
     try:
         path = os.path.join(tmp, "graph.npz")
@@ -399,7 +402,7 @@ def measure_traffic(g, n_nodes):
             d = os.path.join(tmp, tag)
             cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pm", "--",
                                                                  sys.executable, os.path.abspath(__file__), "--pmc-child", path]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=100)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 log("rocprofv3 pass '%s' failed (rc %d): %s" % (tag, r.returncode, r.stderr[-300:]))

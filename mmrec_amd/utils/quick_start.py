@@ -34,8 +34,11 @@ def start_process_group(config, rank, world):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes on this driver)
     on_gpu = getattr(config['device'], 'type', 'cpu') == 'cuda'
-    tdist.init_process_group('nccl' if on_gpu else 'gloo', rank=rank, world_size=world,
-                             **({'device_id': config['device']} if on_gpu else {}))
+    kw = {}
+    if on_gpu:          # Config pinned this process to GPU LOCAL_RANK through CUDA_VISIBLE_DEVICES: it is device 0 here
+        import torch
+        kw['device_id'] = torch.device('cuda', torch.cuda.current_device())
+    tdist.init_process_group('nccl' if on_gpu else 'gloo', rank=rank, world_size=world, **kw)
 
 
 def quick_start(model, dataset, config_dict, save_model=True, mg=False):

@@ -64,7 +64,7 @@ def main():
         train_data.pretrain_setup()
         log("sharded=%s: dataset + loaders %.1fs" % (sharded, time.time() - t))
         if sharded and not dist.is_initialized():
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=config["device"])
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
         t = time.time()
         model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(config["device"])
         torch.cuda.synchronize()
