@@ -237,6 +237,35 @@ def sharded_train_run(dev, rank, world, sh, r_blk, rt_blk, steps):
             "what": "LightGCN L=2 + BPR(2048) + Adam on c5, users sharded x%d / items replicated" % world}
 
 
+def c5_full_eval(dev, rank, world, user_emb, item_emb, eu, ei, n_users, barrier):
+    """The second half of BASELINE.json's metric at config-5 size: full-sort evaluation of ALL 1M users against the 500K
+    items (train positives masked, top-50), users sharded over the ranks, item table replicated -- no exchange in the data
+    path (SURVEY.md 8e "P5 eval: shard users"), so it scales with the GPU count.  Every rank ranks its slice in blocks of
+    20,000 users (the [20,000, 500,000] score block is never formed); users/s = all users / max-over-ranks time."""
+    from mmrec_amd import hip_ops
+    per = -(-n_users // world)
+    lo, hi = min(rank * per, n_users), min((rank + 1) * per, n_users)
+    s, e = np.searchsorted(eu, lo, "left"), np.searchsorted(eu, hi, "left")          # edges are sorted by user
+    rp, col = hip_ops.mask_to_csr(np.stack([eu[s:e] - lo, ei[s:e]]), max(hi - lo, 1), dev)
+    rp_host = rp.cpu().numpy().astype(np.int64)
+    blocks = []
+    for a in range(0, hi - lo, 20_000):
+        b = min(a + 20_000, hi - lo)
+        blocks.append((a, b, (rp[a:b + 1] - rp[a]).contiguous(), col[rp_host[a]:max(rp_host[b], rp_host[a] + 1)].contiguous()))
+
+    def run():
+        out = None
+        for a, b, brp, bcol in blocks:
+            out = hip_ops.score_topk(user_emb[lo + a:lo + b], item_emb, 50, brp, bcol)
+        return out
+    run()
+    barrier()
+    t0 = time.perf_counter()
+    run()
+    barrier()
+    return time.perf_counter() - t0
+
+
 def make_freedom_step(dev, nu, ni, eu, ei, gen, lazy=False):
     """One FREEDOM training step (freedom.py:189-210 + Adam over all 33.6 M parameters incl. the
     trainable 7050 x 4096 / 7050 x 384 feature tables): masked-graph propagation, item-item SpMM,
@@ -633,6 +662,32 @@ def main():
                               "GPUs: independent hyper-parameter runs); `value` is the sharded layout named in "
                               "config.parallelism")
 
+    # companion at every N: full-sort evaluation of all 1M users at config-5 size, users sharded over the ranks
+    c5_eval = None
+    try:
+        ne = nnz_total // 2                       # sym_norm_coo: the first half are the user rows, sorted by (user, item)
+        eu_all, ei_all = r[:ne], c[:ne] - sh.n_users
+        E = bufs[(N_LAYERS - 1) % 2] if (not multi or args.layout == "allgather") else None
+        if E is None:
+            ge = torch.Generator(device=dev).manual_seed(1)
+            Ue = torch.rand(sh.n_users, 64, device=dev, generator=ge) - 0.5
+            Ie = torch.rand(sh.n_items, 64, device=dev, generator=ge) - 0.5
+        elif multi:
+            Ue, Ie = (t.contiguous() for t in sh.unpad(E))
+        else:
+            Ue, Ie = E[:sh.n_users].contiguous(), E[sh.n_users:].contiguous()
+        t_eval = c5_full_eval(dev, rank, world, Ue, Ie, eu_all, ei_all, sh.n_users, fence)
+        if multi:
+            tt = torch.tensor([t_eval], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_eval = float(tt.item())
+        c5_eval = {"users_per_s": sh.n_users / t_eval, "seconds": t_eval,
+                   "what": "score + mask + top-50 of all %d users x %d items (the propagated embeddings of the timed step), "
+                           "users sharded x%d, item table replicated, no exchange" % (sh.n_users, sh.n_items, world)}
+        del Ue, Ie
+    except Exception as ex:
+        c5_eval = {"error": repr(ex)}
+
     # roofline of the dominant kernel family (one SpMM call), from the events of this rank
     call_ms = np.array([s.elapsed_time(e) for s, e, _, _ in ev])
     call_alg = np.array([alg_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
@@ -691,6 +746,7 @@ def main():
                 line["extra"] = {"error": repr(ex)}
         if multi:
             line["extra"] = dist_extra
+        line.setdefault("extra", {})["c5_full_eval"] = c5_eval
         print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()
