@@ -520,21 +520,31 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;   // waves are independent below (wave-level fences only)
+    // everything the wave needs first is requested at once: the loads do not depend on each other, and a wave's life
+    // is a chain of L2 round trips (flag -> mask range -> mask list -> bit words -> query row -> candidate rows)
+    const int gpr = tiles_per_range >> 2, n_words = n_ranges * 2 * gpr;
+    const unsigned long long* row = bits + (size_t)q * n_words;
+    auto word = [&](int wi) -> unsigned long long {
+        const int rg = wi / gpr, g = wi - rg * gpr;               // rg = 2 * range + h
+        // words of tile groups past the last tile are never written by pass 2
+        const bool live = wi < n_words && (rg >> 1) * tiles_per_range + 4 * g < (nc + 31) / 32;
+        return live ? row[wi] : 0ull;
+    };
+    unsigned long long x_next = word(lane);
+    const float4 qv = reinterpret_cast<const float4*>(Q)[(size_t)q * 16 + (lane & 15)];
+    const int fl = flag[q];
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
-    bool bad = flag[q] != 0 || m > F_MASK_LDS;
+    bool bad = fl != 0 || m > F_MASK_LDS;
     if (!bad) {
         // A: decode the pass / fail bits of pass 2 into candidate ids; stage the query's sorted mask list
         for (int e = lane; e < m; e += 64) s_mask[wave][e] = mask_col[m_lo + e];
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const int gpr = tiles_per_range >> 2, n_words = n_ranges * 2 * gpr;
-        const unsigned long long* row = bits + (size_t)q * n_words;
         int n = 0;
         for (int w0 = 0; w0 < n_words; w0 += 64) {
             const int wi = w0 + lane;
-            const int rg = wi / gpr, g = wi - rg * gpr;            // rg = 2 * range + h
-            // words of tile groups past the last tile are never written by pass 2
-            const bool live = wi < n_words && (rg >> 1) * tiles_per_range + 4 * g < (nc + 31) / 32;
-            unsigned long long x = live ? row[wi] : 0ull;
+            const int rg = wi / gpr, g = wi - rg * gpr;
+            unsigned long long x = x_next;
+            if (w0 + 64 < n_words) x_next = word(wi + 64);         // the next word travels while this one is decoded
             const int cbase = ((rg >> 1) * tiles_per_range + 4 * g) * 32 + 4 * (rg & 1);
             for (;;) {
                 const unsigned long long b = __ballot(x != 0ull);
@@ -576,7 +586,6 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
         if (!bad) {
             // C: exact scores, 16 lanes per candidate row, 8 rows in flight per lane
             const int sub = lane & 15, g = lane >> 4;
-            const float4 qv = reinterpret_cast<const float4*>(Q)[(size_t)q * 16 + sub];
             for (int e0 = 0; e0 < valid; e0 += 32) {
                 int id[8];
                 float4 cv[8];
