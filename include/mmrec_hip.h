@@ -63,7 +63,9 @@ const char* mmrec_error_string(int err);
  *      acc_out[r] = acc_scale * (acc_in[r] + y)      (when acc_out != NULL; acc_in may alias acc_out)
  * which is how the LightGCN layer mean (1/(L+1) * sum_l E_l) is accumulated without a stack+mean pass.
  * ---------------------------------------------------------------------------------------------- */
+#ifndef MMREC_SPMM_CHUNK
 #define MMREC_SPMM_CHUNK 512            /* nnz per long-row chunk (one workgroup) */
+#endif
 #define MMREC_SPMM_LONG_ROW_DEFAULT 64  /* default long_row_threshold */
 
 int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals,

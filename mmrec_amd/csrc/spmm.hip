@@ -25,6 +25,10 @@
 #ifndef MMREC_SPMM_LAB
 #define MMREC_SPMM_LAB 0
 #endif
+// matrix rows per 16-lane group of a row block (tools/spmm_sweep.py overrides it)
+#ifndef MMREC_SPMM_RPG
+#define MMREC_SPMM_RPG(n_rows) ((n_rows) <= (1 << 18) ? 1 : 4)
+#endif
 
 namespace {
 
@@ -314,7 +318,7 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     RowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale, nullptr, nullptr, nullptr};
     hipStream_t s = mmrec_stream(stream);
     // small (cache-resident, latency-bound) graphs: one row per 16-lane group; large graphs: four
-    const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
+    const int rows_per_group = MMREC_SPMM_RPG(n_rows);
     const int blocks = (n_rows + 16 * rows_per_group - 1) / (16 * rows_per_group);
     // without a plan every row goes through the row kernel
     const int long_t = n_long > 0 ? long_row_threshold : INT32_MAX;
@@ -349,7 +353,7 @@ extern "C" int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t*
     if (Y == X || scaled == X || acc_out == X) return MMREC_ERR_BAD_ARG;  // other rows still gather from X
     RowEpilogue ep{nullptr, Y, acc_in, acc_out, 1.f, 0.f, 1.f, ego, scaled, w};
     hipStream_t s = mmrec_stream(stream);
-    const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
+    const int rows_per_group = MMREC_SPMM_RPG(n_rows);
     const int blocks = (n_rows + 16 * rows_per_group - 1) / (16 * rows_per_group);
     const int long_t = n_long > 0 ? long_row_threshold : INT32_MAX;
     const int nch = n_long > 0 ? n_chunks : 0;

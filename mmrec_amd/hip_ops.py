@@ -18,7 +18,17 @@ from . import _lib
 
 EMB_DIM = 64
 SPMM_CHUNK = 512
-LONG_ROW_DEFAULT = 64
+LONG_ROW_DEFAULT = None    # by graph size, see default_long_row_threshold
+
+
+def default_long_row_threshold(n_cols):
+    """Rows with more nonzeros than this go to the chunk blocks (16 groups share the row) instead of one 16-lane group.
+    Measured (tools/spmm_sweep.py, profiles/r02_spmm_plan_sweep.log): cache-resident graphs are bound by their longest
+    serial gather chains -- 16 beats 64 by 30-38 % at Baby / Sports / Clothing size; HBM-sized graphs prefer 32 (-4 % at
+    C5; 16 costs 12 % there: too many 256-thread workgroups for 20-nonzero rows).  A function of the COLUMN count only, so
+    a graph and its row blocks (same columns) get the same plan: row shards stay bit-identical to the whole graph."""
+    return 16 if n_cols <= (1 << 18) else 32
+
 TOPK_MAX = 64
 BPR_LOGSIG, BPR_GAMMA = 0, 1
 
@@ -65,7 +75,8 @@ class CsrGraph:
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.nnz = int(colidx.numel())
         self.symmetric = bool(symmetric)
-        self.long_row_threshold = int(long_row_threshold)
+        self.long_row_threshold = int(default_long_row_threshold(self.n_cols) if long_row_threshold is None
+                                      else long_row_threshold)
         self._t = self if symmetric else None
         self._plan(rowptr_host)
 
