@@ -353,6 +353,24 @@ def extra_baby(dev):
             return hip_ops.score_topk(e[:nu].contiguous(), e[nu:].contiguous(), 50, rp, col)
         dt = timeit(evaluate, reps=10, warm=2)
         out["baby_full_eval_users_per_s"] = nu / dt
+        # the same two paths replayed as hipGraphs: at this size an eager call is partly HOST bound (3 + 9 launches of
+        # 4-60 us kernels, ~5 us of Python + launch each); the replay shows what the kernels themselves take
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gp, ge = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gp, stream=side):
+                    hip_ops.lightgcn_mean(g, E0, N_LAYERS)
+                with torch.cuda.graph(ge, stream=side):
+                    evaluate()
+            torch.cuda.current_stream().wait_stream(side)
+            dt = timeit(gp.replay, reps=200, warm=10)
+            out["baby_us_per_layer_graph_replay"] = dt / N_LAYERS * 1e6
+            dt = timeit(ge.replay, reps=50, warm=5)
+            out["baby_full_eval_users_per_s_graph_replay"] = nu / dt
+        except Exception as ex:
+            out["baby_graph_replay_error"] = repr(ex)
         dt = timeit(lambda: hip_ops.score_topk(U, I, 50, rp, col), reps=10, warm=2)
         out["baby_score_topk_ms"] = dt * 1e3
         # fp16 filter on the matrix cores + exact fp32 refinement of the survivors (topk_filter.hip); the rate is
