@@ -34,6 +34,16 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, ids, table):
@@ -67,6 +77,7 @@ class LazyRowEmbedding(nn.Embedding):
         self._opt = None                        # (exp_avg, exp_avg_sq, hyper) once the optimizer has seen us
         self._t = 0                             # optimizer steps taken on this table
         self._last_step = self._owner = self._hist = None
+        self._prefetched = None                 # (ids, event) of a catch-up running on the side stream
 
     # ---- device state, created on first use (the module may have been moved since construction)
     def _state(self):
@@ -97,11 +108,31 @@ class LazyRowEmbedding(nn.Embedding):
             w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._t, b1, b2, eps, wd, _stream()),
             "adam_rows_catchup")       # (the kernel hands the owner marks back: all INT_MAX again)
 
+    def prefetch(self, ids):
+        """Start the catch-up of rows `ids` on a side stream.  The catch-up streams p, m, v of every listed row through HBM
+        (~100 us per table and step at Sports size) and needs nothing the rest of the step produces, while the graph
+        propagation the models run first is a chain of short latency-bound launches that leaves HBM idle: a model that
+        knows its row ids before it propagates calls this first, and the matching `rows(ids)` only waits for the event."""
+        if self._opt is None or self._t == 0 or not ids.is_cuda:
+            return
+        ids = ids.contiguous()
+        side = _side_stream(ids.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            self._catch_up(ids)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._prefetched = (ids, done)
+
     def rows(self, ids):
         """up-to-date rows `ids` [len(ids), F], differentiable w.r.t. the table"""
         ids = ids.contiguous()
-        with torch.no_grad():
-            self._catch_up(ids)
+        pf, self._prefetched = getattr(self, '_prefetched', None), None
+        if pf is not None:
+            torch.cuda.current_stream().wait_event(pf[1])       # (also when the ids differ: the table must be quiet)
+        if pf is None or pf[0].data_ptr() != ids.data_ptr() or pf[0].numel() != ids.numel():
+            with torch.no_grad():
+                self._catch_up(ids)
         return _GatherRows.apply(self.weight, ids, self)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):

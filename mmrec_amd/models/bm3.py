@@ -37,6 +37,7 @@ class BM3(FusedEvalMixin, GeneralRecommender):
         self.lazy_projection = True if lazy is None else bool(lazy)
         n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
         self.lazy_feature_adam = lazy_adam_enabled(config, n_feat) and self.lazy_projection
+        self.lazy_prefetch = config['lazy_prefetch'] is not False    # new key: catch-up on a side stream (default on)
         table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
         if self.lazy_feature_adam:
             self.graph_capturable = False
@@ -76,6 +77,10 @@ class BM3(FusedEvalMixin, GeneralRecommender):
             return [F.dropout(t.detach().clone(), self.dropout) for t in tensors]
 
     def calculate_loss(self, interactions):
+        if self.lazy_projection and self.lazy_feature_adam and self.lazy_prefetch:   # row catch-up on the side stream
+            for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
+                if emb is not None:
+                    emb.prefetch(interactions[1])
         u_ori, i_ori = self.forward()
         u_ori, i_ori = u_ori.contiguous(), i_ori.contiguous()
         users, items = interactions[0], interactions[1]

@@ -77,6 +77,7 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
         # gathered-rows projection a step then reads / writes only the <= 2B feature rows of its batch
         n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
         self.lazy_feature_adam = lazy_adam_enabled(config, n_feat) and self.lazy_projection
+        self.lazy_prefetch = config['lazy_prefetch'] is not False    # new key: catch-up on a side stream (default on)
         self.n_nodes = self.n_users + self.n_items
 
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
@@ -138,6 +139,13 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
 
     def calculate_loss(self, interaction):
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
+        rows = None
+        if self.lazy_projection:
+            rows = torch.cat((pos_items, neg_items))
+            if self.lazy_feature_adam and self.lazy_prefetch:      # the row catch-up streams through HBM under the propagation
+                for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
+                    if emb is not None:
+                        emb.prefetch(rows)
         ua, ia = self.forward(self.masked_adj)
         self.build_item_graph = False
         loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
@@ -148,7 +156,6 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
             # feature row only, so projecting the <= 2B gathered rows is the same function and the same
             # gradient (dW, db, and dX scattered back into the table): 2.1 GFLOP regardless of n_items
             # instead of 3.7 (Baby) / 9.6 (Sports) / 262 (500K items).
-            rows = torch.cat((pos_items, neg_items))
             b = pos_items.shape[0]
             lp = torch.arange(b, device=rows.device)
             ln = lp + b

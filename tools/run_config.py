@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--device-neg-sampling", action="store_true")
     ap.add_argument("--graph-step", action="store_true", help="replay the training step as a hipGraph (every model that does not opt out)")
+    ap.add_argument("--no-prefetch", action="store_true", help="row-lazy Adam: catch-up on the main stream (A/B of lazy_prefetch)")
     ap.add_argument("--eager", action="store_true", help="never replay (default: the plugins that declare graph_capturable)")
     ap.add_argument("--dense-adam", action="store_true", help="force the dense fused Adam on the trainable feature tables "
                                                                "(FREEDOM, BM3 default to the row-lazy exact Adam)")
@@ -81,6 +82,8 @@ def main():
               save_recommended_topk=False, device_neg_sampling=args.device_neg_sampling)
     if args.graph_step or args.eager:
         cd['hip_graph_step'] = bool(args.graph_step)       # default: 'auto' (overall.yaml)
+    if args.no_prefetch:
+        cd['lazy_prefetch'] = False
     if args.dense_adam:
         cd['lazy_feature_adam'] = False
     config = Config(model_name, ds, cd)
