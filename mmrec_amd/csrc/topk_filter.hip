@@ -58,6 +58,8 @@ constexpr int F_CAPQ = 256;    // survivor slots per query over all ranges
 constexpr int F_MINR = 8, F_MAXR = 16;   // candidate ranges: 256..512 group maxima per query
 constexpr int F_SLOW_WAVES = 8;   // waves sharing one query of the slow queue
 constexpr int F_SLOW_MASK_LDS = 4096;   // mask entries of such a query staged in LDS
+constexpr int F_SLOW_PARTS = 4096;      // (query, split) partial top-k lists of the split slow path (2 MiB)
+constexpr int F_SLOW_SPLIT_NC = 65536;  // from this many candidates on a flagged query is split over 16 workgroups
 constexpr int F_MIN_NC = 4096;    // below: the materialised path is as fast (fixed launch costs)
 constexpr int F_PF = 4;        // 64-candidate stages in flight per workgroup (register ring)
 constexpr int F_MASK_LDS = 512; // mask entries per query staged in LDS by the final kernel (>= F_MAXR * 32)
@@ -437,14 +439,19 @@ __device__ __forceinline__ Cand sort_best64(const unsigned long long* list, int 
 // after every compaction (its later ids are larger: ties lose); wave 0 merges the waves' top-k lists (the global
 // top-k under (score desc, id asc) is contained in their union).  One wave per query took 80-200 us per evaluation
 // batch for the handful of heavy users it typically holds.
+// [st0, st1): the 64-candidate steps this workgroup takes; `part` != nullptr: the workgroup's sorted top-k goes there
+// (64 packed entries) instead of the outputs -- large candidate sets are split over several workgroups per query and
+// merged by filter_slow_merge_kernel (one workgroup streaming 500K candidates for ONE flagged query took 5 ms, as long
+// as the whole 20,000-query block of the fast path).
 __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
                                           const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
                                           int q, unsigned long long (*lists)[F_CAPQ], unsigned long long* merged,
                                           int32_t* mask_lds, int lane, int wave, int64_t* __restrict__ out_idx,
-                                          float* __restrict__ out_val) {
+                                          float* __restrict__ out_val, int st0, int st1,
+                                          unsigned long long* __restrict__ part) {
     unsigned long long* list = lists[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int steps = (nc + 63) / 64;
+    const int steps = st1;
     q = __builtin_amdgcn_readfirstlane(q);
     const float4* q4 = reinterpret_cast<const float4*>(Q) + (size_t)q * 16;   // wave-uniform: scalar loads
     // the query's sorted mask list: binary-searched per candidate, from LDS when it fits (heavy users are what this
@@ -459,7 +466,7 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     __syncthreads();
     float teff = -INFINITY;
     int cnt = 0;
-    for (int it = wave;; it += F_SLOW_WAVES) {
+    for (int it = st0 + wave;; it += F_SLOW_WAVES) {
         const bool last = it >= steps;
         if (!last) {
             const int c = it * 64 + lane;
@@ -500,7 +507,9 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     __syncthreads();
     if (wave == 0) {
         const Cand y = sort_best64(merged, F_SLOW_WAVES * 64, lane);
-        if (lane < k) {
+        if (part) {
+            part[lane] = pack_cand(lane < k ? y.v : -INFINITY, lane < k ? y.i : INT_MAX);
+        } else if (lane < k) {
             const bool ok = y.i != INT_MAX;
             out_idx[(size_t)q * k + lane] = ok ? (int64_t)y.i : (int64_t)-1;
             if (out_val) out_val[(size_t)q * k + lane] = ok ? y.v : -INFINITY;
@@ -614,17 +623,48 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
 
 // The queue of the final kernel, served by persistent workgroups (inlining slow_topk into the final kernel doubled
 // its registers and its time: 53 -> 122 us on the Baby evaluation with an empty queue).
+// splits per flagged query: `want` (host: by the candidate count) as long as the (query, split) partial lists fit the
+// F_SLOW_PARTS-entry buffer; 1 = the workgroup writes the outputs itself
+__device__ __forceinline__ int slow_splits(int nf, int want) {
+    return nf > 0 ? max(1, min(want, F_SLOW_PARTS / nf)) : 1;
+}
+
 __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
     const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col, const int* __restrict__ flist,
-    const int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    const int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val, int want_splits,
+    unsigned long long* __restrict__ parts) {
     __shared__ unsigned long long s_l[F_SLOW_WAVES][F_CAPQ];
     __shared__ unsigned long long s_m[F_SLOW_WAVES * 64];
     __shared__ int32_t s_mask[F_SLOW_MASK_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nf = *n_flagged;
-    for (int j = blockIdx.x; j < nf; j += gridDim.x)   // uniform per workgroup
-        slow_topk(Q, C, nc, k, mask_rowptr, mask_col, flist[j], s_l, s_m, s_mask, lane, wave, out_idx, out_val);
+    const int S = slow_splits(nf, want_splits), steps = (nc + 63) / 64;
+    for (int w = blockIdx.x; w < nf * S; w += gridDim.x) {   // uniform per workgroup
+        const int j = w / S, sp = w - j * S;
+        const int st0 = (int)((long long)steps * sp / S), st1 = (int)((long long)steps * (sp + 1) / S);
+        slow_topk(Q, C, nc, k, mask_rowptr, mask_col, flist[j], s_l, s_m, s_mask, lane, wave, out_idx, out_val, st0, st1,
+                  S > 1 ? parts + (size_t)w * 64 : nullptr);
+    }
+}
+
+// one wave per flagged query whose candidates were split: the S sorted partial lists -> the outputs
+__global__ __launch_bounds__(256) void filter_slow_merge_kernel(const int* __restrict__ flist, const int* __restrict__ n_flagged,
+                                                               int want_splits, const unsigned long long* __restrict__ parts,
+                                                               int k, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nf = *n_flagged;
+    const int S = slow_splits(nf, want_splits);
+    if (S <= 1) return;
+    for (int j = blockIdx.x * 4 + wave; j < nf; j += gridDim.x * 4) {
+        const Cand y = sort_best64(parts + (size_t)j * S * 64, S * 64, lane);
+        const int q = flist[j];
+        if (lane < k) {
+            const bool ok = y.i != INT_MAX;
+            out_idx[(size_t)q * k + lane] = ok ? (int64_t)y.i : (int64_t)-1;
+            if (out_val) out_val[(size_t)q * k + lane] = ok ? y.v : -INFINITY;
+        }
+    }
 }
 
 struct FilterPlan {
@@ -664,7 +704,8 @@ bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
 size_t topk64_filter_workspace_bytes(int nq, int nc, int k) {
     const FilterPlan p = filter_plan(nq, nc);
     return al256f((size_t)p.nq_pad * 128) + al256f((size_t)p.n_stages * 64 * 128) + al256f((size_t)p.nq_pad * 4) + 512 +
-           al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f((size_t)nq * p.R * p.spr * 8);
+           al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f((size_t)nq * p.R * p.spr * 8) +
+           al256f((size_t)F_SLOW_PARTS * 64 * 8);
 }
 
 int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,
@@ -683,6 +724,8 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     int* flag = reinterpret_cast<int*>(ws);            ws += al256f((size_t)nq * 4);
     int* flist = reinterpret_cast<int*>(ws);           ws += al256f((size_t)nq * 4);
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws);   // [nq][R][2][spr / 2]
+    ws += al256f((size_t)nq * p.R * p.spr * 8);
+    unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][64]
     hipError_t e = hipMemsetAsync(stats, 0, 512, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, stats);
@@ -699,7 +742,11 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
     hipLaunchKernelGGL(filter_final_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
                        mask_col, bits, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+    const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
     hipLaunchKernelGGL(filter_slow_kernel, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
-                       n_flagged, out_idx, out_val);
+                       n_flagged, out_idx, out_val, want, parts);
+    if (want > 1)
+        hipLaunchKernelGGL(filter_slow_merge_kernel, dim3(64), dim3(256), 0, s, flist, n_flagged, want, parts, k, out_idx,
+                           out_val);
     MMREC_RETURN_LAUNCH_STATUS();
 }

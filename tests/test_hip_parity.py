@@ -533,6 +533,33 @@ def test_topk_filter_path_edge_cases(ops, dev, monkeypatch):
             assert abs(s64[r, j] - s64[r, order[-1]]) <= 2e-6 * unit, (r, j)
 
 
+def test_topk_slow_queue_split_over_workgroups(ops, dev):
+    """>= 65,536 candidates: a query the filter cannot serve is split over 16 workgroups whose partial top-k lists are
+    merged (one workgroup streaming 500K candidates for one flagged query took as long as a whole 20,000-query block).
+    (a) all scores tie: every query is flagged; lowest unmasked ids win, masked ids at -1e10 fill a short list;
+    (b) random data, two heavy users (k + #masked > the 512 group maxima) among ordinary ones: the oracle's top-k."""
+    nq, nc, k = 6, 70_000, 20
+    Q, C = np.ones((nq, 64), np.float32), np.zeros((nc, 64), np.float32)
+    rows = np.concatenate([np.repeat(0, nc - 7), np.repeat(np.arange(1, nq), 2)])
+    cols = np.concatenate([np.arange(3, nc - 4), np.tile(np.array([0, 5]), nq - 1)])
+    rp, col = ops.mask_to_csr(np.stack([rows, cols]), nq, dev)
+    idx, val = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    assert idx[0, :7].tolist() == [0, 1, 2] + list(range(nc - 4, nc)) and idx[0, 7:].tolist() == list(range(3, 16))
+    assert np.all(val[0, :7] == 0) and np.all(val[0, 7:] == np.float32(-1e10))
+    for r in range(1, nq):
+        assert idx[r].tolist() == [c for c in range(30) if c not in (0, 5)][:k] and np.all(val[r] == 0)
+    rng = np.random.default_rng(11)
+    nq = 40
+    Qr = rng.standard_normal((nq, 64)).astype(np.float32) * 0.2
+    Cr = rng.standard_normal((nc, 64)).astype(np.float32) * 0.2
+    heavy = {3: rng.choice(nc, 700, replace=False), 17: rng.choice(nc, 5000, replace=False)}
+    rows = np.concatenate([np.repeat(q, len(v)) for q, v in heavy.items()] + [np.arange(nq)])
+    cols = np.concatenate([v for v in heavy.values()] + [rng.integers(0, nc, nq)])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    _topk_check(ops, dev, Qr, Cr, 50, np.stack([key // nc, key % nc]))
+
+
 def test_topk_knn_shape(ops, dev, golden):
     """P6: kNN(k=10) over row-normalised features == freedom.py:79-82 on the golden features."""
     for key, k in (("image_feat", 10), ("text_feat", 10)):
