@@ -27,6 +27,10 @@ def default_long_row_threshold(n_cols):
     serial gather chains -- 16 beats 64 by 30-38 % at Baby / Sports / Clothing size; HBM-sized graphs prefer 32 (-4 % at
     C5; 16 costs 12 % there: too many 256-thread workgroups for 20-nonzero rows).  A function of the COLUMN count only, so
     a graph and its row blocks (same columns) get the same plan: row shards stay bit-identical to the whole graph."""
+    import os
+    forced = os.environ.get("MMREC_LONG_ROW_THRESHOLD")      # measurement aid (tools/, A/B runs of bench.py)
+    if forced:
+        return int(forced)
     return 16 if n_cols <= (1 << 18) else 32
 
 TOPK_MAX = 64
