@@ -354,3 +354,135 @@ def test_knn_graph_at_sports_item_count(F):
     rows = np.sort(np.random.default_rng(F).choice(n, min(1024, n), False))
     s = (Xn[rows].double() @ Xn.double().t()).float()
     topk_rows_match(idx, s, np.zeros((2, 0), dtype=np.int64), 10, rows)
+
+
+# ------------------------------------------------------------------------------------------------ vs the REFERENCE itself
+def _shapes_golden():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes.npz"), allow_pickle=False))
+
+
+def _check_against_fingerprint(model, g, prefix, tag, cancelling=()):
+    """every gradient against what tests/golden/make_golden_shapes.py recorded from the unmodified reference: Frobenius
+    norm (1e-5), sum, and the recorded rows (whole small tensors)"""
+    for name, p in model.named_parameters():
+        key = prefix + "g_" + name
+        if key + "_norm" not in g:
+            continue
+        grad = p.grad.detach().cpu()
+        if name in cancelling:                      # analytically zero: rounding noise on both sides (see check_grads)
+            assert float(grad.abs().max()) <= 1e-6 * cancelling[name] and g[key + "_norm"] <= 1e-6 * cancelling[name] * 64
+            continue
+        norm = float(grad.double().norm())
+        assert abs(norm - g[key + "_norm"]) <= 1e-5 * g[key + "_norm"], (tag, name, norm, g[key + "_norm"])
+        vals = grad[torch.as_tensor(g[key + "_rows"])] if key + "_rows" in g else grad
+        ref = g[key + "_vals"]
+        np.testing.assert_allclose(vals.numpy(), ref, rtol=1e-4, atol=1e-5 * max(float(np.abs(ref).max()), 1e-30),
+                                   err_msg="%s d%s" % (tag, name))
+        scale = g[key + "_norm"] * np.sqrt(grad.numel())
+        assert abs(float(grad.double().sum()) - g[key + "_sum"]) <= 1e-5 * scale, (tag, name, "sum")
+
+
+def _check_eval_against_golden(model, config, valid_data, g, prefix):
+    """the reference Trainer's metric dict (identical to 1e-4) and its top-50 lists of 512 sampled users (same ids up to
+    near-ties at the cut: these are UNTRAINED embeddings, scores are densely packed)"""
+    from mmrec_amd.common.trainer import Trainer
+    res = Trainer(config, model).evaluate(valid_data)
+    for k, v in zip(g[prefix + "metric_keys"], g[prefix + "metrics"]):
+        assert abs(res[str(k)] - v) <= 1e-4 + 1e-12, (k, res[str(k)], v)
+    batches = list(valid_data)
+    users, mask = batches[0][0], batches[0][1]
+    idx = model.full_sort_topk(batches[0], 50).cpu().numpy()
+    rows, ref = g[prefix + "topk_rows"], g[prefix + "topk"].astype(np.int64)
+    rows = rows[rows < idx.shape[0]]
+    with torch.no_grad():
+        u, i = model._cached_eval_embeddings()
+        s = (u[users[torch.as_tensor(rows).to(users.device)]] @ i.t()).cpu()
+    lm = local_mask(mask[0].cpu().numpy(), mask[1].cpu().numpy(), rows)
+    s[torch.as_tensor(lm[0]), torch.as_tensor(lm[1])] = -1e10
+    same = 0
+    for j, r in enumerate(rows):
+        a, b = set(idx[r].tolist()), set(ref[j].tolist())
+        same += a == b
+        unit = max(float(s[j][s[j] > -1e9].abs().max()), 1e-30)
+        kth = float(torch.topk(s[j], 50)[0][-1])
+        for c in a ^ b:
+            assert abs(float(s[j][c]) - kth) <= 2e-6 * unit, (prefix, r, c)
+    assert same >= 0.95 * len(rows), same
+
+
+def test_freedom_step_vs_reference_golden_at_sports_shape(tmp_path):
+    """BASELINE config 3 against THE REFERENCE ITSELF (tests/golden/shapes.npz, written by the unmodified reference on the
+    same synthetic Amazon-Sports-shaped dataset, seed 999): same initial parameters, same first batch, the reference's own
+    multinomial draw replayed, its frozen item-item graph shared as its cache file would be -- forward rows, loss, every
+    gradient (norm, sum, sampled rows), the evaluation metrics and sampled top-50 lists.  Also: the item-item graph built
+    by the device top-K kernel at 18,357 items x 4096 / 384 features agrees with the reference's (near-tie neighbours aside)."""
+    from mmrec_amd import hip_ops
+    g = _shapes_golden()
+    config, train_data, valid_data, model = build_shape(tmp_path, "FREEDOM", "sports",
+                                                        {"dropout": 0.8, "reg_weight": 1e-3, "lazy_feature_adam": False})
+    dev = model.device
+    np.testing.assert_array_equal(model.user_embedding.weight.detach().cpu()[g["fr_rows_u"]].numpy(), g["fr_init_user"])
+    np.testing.assert_array_equal(model.image_trs.weight.detach().cpu()[:, :64].numpy(), g["fr_init_image_W"])
+    batch = next(iter(train_data))
+    np.testing.assert_array_equal(batch.cpu().numpy(), g["fr_batch"])
+    ni = model.n_items
+    ref_idx, ref_val = g["fr_mm_idx"].astype(np.int64), g["fr_mm_vals"]
+    mine = orc.coalesce_coo(*model.mm_adj.to_coo_host(), ni, ni)
+    theirs = orc.coalesce_coo(ref_idx, ref_val, ni, ni)
+    agree = len(set(map(tuple, mine[0].T)) & set(map(tuple, theirs[0].T))) / theirs[0].shape[1]
+    assert agree > 0.995, agree                        # near-tie neighbours may differ (fp32 accumulation order)
+    model.mm_adj = hip_ops.CsrGraph.from_coo_host(ref_idx, ref_val, ni, ni, dev)
+    model.mm_adj.transpose()
+    model.set_kept_edges(torch.as_tensor(g["fr_keep_idx"].astype(np.int64)).to(dev))
+    with torch.no_grad():
+        u, i = model.forward(model.masked_adj)
+    close_scaled(u[torch.as_tensor(g["fr_rows_u"]).to(dev)], g["fr_user_out"], what="user rows vs reference")
+    close_scaled(i[torch.as_tensor(g["fr_rows_i"]).to(dev)], g["fr_item_out"], what="item rows vs reference")
+    for lazy in (False, True):
+        model.zero_grad()
+        model.lazy_projection = lazy
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(g["fr_loss"]), rtol=1e-5)
+        _check_against_fingerprint(model, g, "fr_", "FREEDOM/sports vs reference lazy=%s" % lazy,
+                                   cancelling={"image_trs.bias": 1e-3, "text_trs.bias": 1e-3})
+    model.zero_grad()
+    model.eval()
+    _check_eval_against_golden(model, config, valid_data, g, "fr_")
+
+
+def test_bm3_step_vs_reference_golden_at_clothing_shape(tmp_path, monkeypatch):
+    """BASELINE config 4 against THE REFERENCE ITSELF at Amazon-Clothing shape: same initial parameters and batch, the
+    reference's four F.dropout keep-masks replayed -- loss, every gradient, evaluation metrics and sampled top-50 lists."""
+    g = _shapes_golden()
+    config, train_data, valid_data, model = build_shape(tmp_path, "BM3", "clothing",
+                                                        {"n_layers": 2, "dropout": 0.3, "reg_weight": 0.1,
+                                                         "lazy_feature_adam": False})
+    dev = model.device
+    np.testing.assert_array_equal(model.user_embedding.weight.detach().cpu()[g["bm3_rows_u"]].numpy(), g["bm3_init_user"])
+    batch = next(iter(train_data))
+    np.testing.assert_array_equal(batch.cpu().numpy(), g["bm3_batch"])
+    masks_cpu = []
+    for nm in "uitv":
+        shape = tuple(int(x) for x in g["bm3_mask_%s_shape" % nm])
+        bits = np.unpackbits(g["bm3_mask_" + nm])[:shape[0] * shape[1]].reshape(shape)
+        masks_cpu.append(torch.from_numpy(bits.astype(np.float32)))
+    import mmrec_amd.models.bm3 as bm3mod
+    real_dropout = bm3mod.F.dropout
+    for lazy in (False, True):
+        model.zero_grad()
+        model.lazy_projection = lazy
+        masks = [m.to(dev) for m in masks_cpu]
+
+        def replay(x, p=0.5, training=True, inplace=False):
+            return x * masks.pop(0) / (1.0 - p)
+        monkeypatch.setattr(bm3mod.F, "dropout", replay)
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(g["bm3_loss"]), rtol=1e-5)
+        _check_against_fingerprint(model, g, "bm3_", "BM3/clothing vs reference lazy=%s" % lazy)
+    monkeypatch.setattr(bm3mod.F, "dropout", real_dropout)
+    model.zero_grad()
+    model.eval()
+    _check_eval_against_golden(model, config, valid_data, g, "bm3_")
