@@ -133,3 +133,48 @@ def test_freedom_trained_epoch_at_baby_shape(tmp_path):
         fm.FREEDOM.__init__ = real_init
     print("FREEDOM/baby: epoch loss device %.6f oracle %.6f; recall@20 %.4f / %.4f" %
           (out[0], out[1], out[2]["recall@20"], out[3]["recall@20"]))
+
+
+# ------------------------------------------------------------------------------------------------ vs the REFERENCE itself
+def _run_vs_reference(tmp_path, model_name, hyper, tag):
+    """The same epoch the unmodified reference trained (tests/golden/baby_epoch.npz, make_golden_baby_epoch.py): same seed
+    and dataset -> same initial parameters and batches; the reference's multinomial draw (and, for FREEDOM, its frozen
+    item-item graph) replayed; default Trainer settings (fused Adam, hipGraph replay where the plugin allows it)."""
+    import os
+    from mmrec_amd import hip_ops
+    from mmrec_amd.common.trainer import Trainer
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baby_epoch.npz"), allow_pickle=False))
+    dev = torch.device("cuda:0")
+    config, train_data, valid_data, model = S.build_shape(tmp_path, model_name, "baby", hyper)
+    if tag + "mm_idx" in g:
+        ni = model.n_items
+        model.mm_adj = hip_ops.CsrGraph.from_coo_host(g[tag + "mm_idx"].astype(np.int64), g[tag + "mm_vals"], ni, ni, dev)
+        model.mm_adj.transpose()
+    model.set_kept_edges(torch.as_tensor(g[tag + "keep_idx"].astype(np.int64)).to(dev))
+    trainer = Trainer(config, model)
+    loss, _ = trainer._train_epoch(train_data, 0)
+    np.testing.assert_allclose(loss, float(g[tag + "epoch_loss"]), rtol=1e-4)
+    res = trainer.evaluate(valid_data)
+    for k, v in zip(g[tag + "metric_keys"], g[tag + "metrics"]):
+        assert abs(res[str(k)] - v) <= 1e-4 + 1e-12, (k, res[str(k)], v)
+    for name, p in model.named_parameters():
+        if name.endswith("trs.bias"):
+            continue                                  # analytically-zero gradient: Adam-normalised rounding noise
+        w = p.detach().cpu()
+        ref_norm = float(g[tag + "p_" + name + "_norm"])
+        assert abs(float(w.double().norm()) - ref_norm) <= 1e-4 * ref_norm, name
+        rows = torch.as_tensor(g[tag + "p_" + name + "_rows"])
+        vals = w[rows][:, :64] if w.dim() == 2 else w
+        ref = g[tag + "p_" + name + "_vals"]
+        assert np.abs(vals.numpy() - ref).max() <= 1e-4 * max(float(np.abs(ref).max()), 1e-30), name
+    return loss, float(g[tag + "epoch_loss"]), res["recall@20"], dict(zip(g[tag + "metric_keys"], g[tag + "metrics"]))["recall@20"]
+
+
+def test_layergcn_trained_epoch_vs_reference_golden(tmp_path):
+    out = _run_vs_reference(tmp_path, "LayerGCN", {"n_layers": 4, "dropout": 0.1, "reg_weight": 1e-3}, "lay_")
+    print("LayerGCN/baby vs reference: epoch loss %.4f / %.4f, recall@20 %.4f / %.4f" % out)
+
+
+def test_freedom_trained_epoch_vs_reference_golden(tmp_path):
+    out = _run_vs_reference(tmp_path, "FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3}, "fr_")
+    print("FREEDOM/baby vs reference: epoch loss %.6f / %.6f, recall@20 %.4f / %.4f" % out)
