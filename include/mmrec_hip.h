@@ -315,6 +315,7 @@ int mmrec_cosine_bwd_f32(const float* X, const int64_t* ix, const float* Y, cons
  * row is next needed -- results equal the dense update bit for bit.
  *   hist     [capacity][2] fp32: step-dependent scalars of optimizer step t, written by mmrec_adam_hist_set(t)
  *   last_step[n_rows] int32: steps already applied per row (0 initially)
+ *   ids may hold -1 = "no row" (a slot served elsewhere, e.g. by another rank's shard of the table): skipped everywhere.
  *   owner    [n_rows] int32, INT_MAX where idle: mmrec_adam_rows_owner marks the first position of every row in `ids`
  *            (duplicates allowed); catchup / step consume the marks (entries are INT_MAX again afterwards)
  *   catchup: bring the rows of `ids` (ids == NULL: all n_rows rows) to step t_now

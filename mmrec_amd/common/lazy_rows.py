@@ -48,6 +48,9 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, ids, table):
         ctx.table, ctx.ids = table, ids
+        if table.allow_missing:          # ids of -1 = "no row": a zero row forward, no gradient, no optimizer work
+            present = ids >= 0
+            return weight.detach().index_select(0, ids.clamp_min(0)) * present.unsqueeze(1).to(weight.dtype)
         return weight.detach().index_select(0, ids)
 
     @staticmethod
@@ -78,6 +81,7 @@ class LazyRowEmbedding(nn.Embedding):
         self._t = 0                             # optimizer steps taken on this table
         self._last_step = self._owner = self._hist = None
         self._prefetched = None                 # (ids, event) of a catch-up running on the side stream
+        self.allow_missing = False              # True: rows(ids) accepts -1 = "no row" (item-sharded tables: slots of other ranks)
 
     # ---- device state, created on first use (the module may have been moved since construction)
     def _state(self):
@@ -167,7 +171,12 @@ class LazyRowEmbedding(nn.Embedding):
         # occurrence sums the row's occurrences itself, in position order (deterministic; no zero-fill + index_add_ pass
         # over the [n, F] gradient); id lists too long for its LDS position list are pre-summed into the owner slots
         presummed = n > MAX_IDS
-        g = torch.zeros_like(dY).index_add_(0, self._owner.index_select(0, ids).long(), dY) if presummed else dY
+        if presummed:
+            present = ids >= 0                      # (-1 = "no row": its gradient row is dropped)
+            slots = self._owner.index_select(0, ids.clamp_min(0)).long()
+            g = torch.zeros_like(dY).index_add_(0, slots[present], dY[present])
+        else:
+            g = dY
         _lib.check(lib.mmrec_adam_rows_step_f32(_p(w), _p(m), _p(v), _p(ids), _p(self._owner), _p(g), n, w.shape[1],
                                                 _p(self._last_step), self._t, float(lr), b1, b2, eps, wd, int(presummed),
                                                 _stream()),

@@ -189,7 +189,7 @@ __global__ void adam_hist_set_kernel(float2* __restrict__ hist, int t, float a, 
 
 __global__ __launch_bounds__(256) void adam_rows_owner_kernel(const int64_t* __restrict__ ids, int n, int* __restrict__ owner) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicMin(owner + ids[i], i);
+    if (i < n && ids[i] >= 0) atomicMin(owner + ids[i], i);    // id < 0: "no row" (a slot another rank serves)
 }
 
 // ids == nullptr: every row (flush).  One workgroup per listed row.  The row stays in registers while the steps
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
     float beta1, float beta2, float eps, float weight_decay) {
     __shared__ float2 s_h[256];
     const int64_t row = ids ? ids[blockIdx.x] : (int64_t)blockIdx.x;
+    if (row < 0) return;                                // "no row"
     if (ids && owner[row] != (int)blockIdx.x) return;   // a duplicate: the first occurrence does the work
     const int s0 = last_step[row];
     __syncthreads();                                    // everybody has read last_step / owner before they change
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(
     __shared__ int s_wave[4];
     __shared__ int s_total;
     const int64_t row = ids[blockIdx.x];
-    if (owner[row] != (int)blockIdx.x) return;
+    if (row < 0 || owner[row] != (int)blockIdx.x) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_total = 0;
     __syncthreads();

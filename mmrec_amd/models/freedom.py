@@ -350,8 +350,11 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         """[2B, 64] projected feature rows of the batch items, each computed by the rank that owns the item"""
         from mmrec_amd.dist import exchange_owned_rows
         owned = (rows >= self.item_lo) & (rows < self.item_hi)
-        local = torch.where(owned, rows - self.item_lo, torch.zeros_like(rows))
-        feats = emb.rows(local) if self.lazy_feature_adam else emb.weight[local]
+        if self.lazy_feature_adam:        # slots of other ranks' items: -1 = "no row" (no catch-up, no gradient, no step)
+            emb.allow_missing = True
+            feats = emb.rows(torch.where(owned, rows - self.item_lo, torch.full_like(rows, -1)))
+        else:
+            feats = emb.weight[torch.where(owned, rows - self.item_lo, torch.zeros_like(rows))]
         w, b = _SumGradOverRanks.apply(trs.weight, self.group), _SumGradOverRanks.apply(trs.bias, self.group)
         return exchange_owned_rows(hip_ops.linear(feats, w, b), owned, group=self.group, multi=self.world > 1 or self.force)
 

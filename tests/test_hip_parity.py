@@ -837,6 +837,33 @@ def test_lazy_row_adam_equals_dense(dev):
         assert torch.equal(ol, od) and opt_l.state[lazy.weight]["step"] == 12
 
 
+def test_lazy_row_adam_skips_missing_rows(dev):
+    """item-sharded feature tables (ShardedFREEDOM): a batch slot whose item another rank owns is id -1 = "no row" -- a
+    zero row forward, no gradient, no catch-up / step work; the present rows evolve exactly as under dense Adam."""
+    from mmrec_amd.common.lazy_rows import LazyRowEmbedding
+    from mmrec_amd.common.optim import HipAdam
+    g = torch.Generator().manual_seed(5)
+    w0 = torch.randn(50, 64, generator=g)
+    dense = torch.nn.Embedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    lazy = LazyRowEmbedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    lazy.allow_missing = True
+    opt_d, opt_l = HipAdam([dense.weight], lr=1e-2), HipAdam([lazy.weight], lr=1e-2)
+    for step in range(6):
+        ids = torch.randint(0, 50, (40,), generator=g)
+        ids[torch.rand(40, generator=g) < 0.6] = -1                    # most slots belong to other ranks
+        coef = (torch.randint(-16, 17, (40, 64), generator=g).float() / 16).to(dev)
+        ids = ids.to(dev)
+        present = ids >= 0
+        rows_l = lazy.rows(ids)
+        rows_d = dense.weight[ids.clamp_min(0)] * present.unsqueeze(1)
+        assert torch.equal(rows_l, rows_d) and torch.all(rows_l[~present] == 0)
+        opt_d.zero_grad(), opt_l.zero_grad()
+        (rows_d * coef).sum().backward(), (rows_l * coef).sum().backward()
+        opt_d.step(), opt_l.step()
+    lazy.flush()
+    assert torch.equal(lazy.weight, dense.weight)
+
+
 # ---------------------------------------------------------------------------------------- Baby shape, end to end
 def test_baby_shape_forward_eval_recall_vs_oracle(ops, dev):
     """north_star's accuracy target at the full Amazon-Baby shape (19,445 x 7,050, 118,706 train
