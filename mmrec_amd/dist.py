@@ -137,18 +137,39 @@ class BipartiteSharding:
                 out.append((kind, c) + sp.chunk_out(rank, c) + sp.chunk_region(c))
         return out
 
-    def rank_blocks(self, rows, cols, vals, rank, make_csr):
+    def rank_blocks(self, rows, cols, vals, rank, make_csr, node_cols=False):
         """This rank's row chunks of the adjacency given as COO over NODE ids (items offset by n_users), any order:
-        -> (user chunk blocks, item chunk blocks), each `make_csr(local_rows, padded_cols, vals, n_rows, n_cols)`.
-        Entries keep their COO order inside a row (make_csr must be stable), so a row sums exactly as on one GPU."""
+        -> (user chunk blocks, item chunk blocks), each `make_csr(local_rows, cols, vals, n_rows, n_cols)`.
+        Entries keep their COO order inside a row (make_csr must be stable), so a row sums exactly as on one GPU.
+        node_cols: column ids stay NODE ids (the block multiplies a table in node order: the first layer reads the
+        replicated parameters without a permutation into the padded space); default: padded positions."""
         rows = np.asarray(rows, dtype=np.int64)
         pr, pc = self.padded_coo(rows, cols)
+        if node_cols:
+            pc = np.asarray(cols, dtype=np.int64)
         vals = np.asarray(vals)
         blocks = {"u": [], "i": []}
         for kind, c, lo, hi, _, _ in self.entries(rank):
             sel = np.nonzero((pr >= lo) & (pr < hi))[0]
-            blocks[kind].append(make_csr(pr[sel] - lo, pc[sel], vals[sel], hi - lo, self.N_pad))
+            blocks[kind].append(make_csr(pr[sel] - lo, pc[sel], vals[sel], hi - lo,
+                                         self.n_users + self.n_items if node_cols else self.N_pad))
         return blocks["u"], blocks["i"]
+
+    def own_row_slices(self, table, rank):
+        """Per entry of `rank`: the [chunk rows, d] rows of the node-order `table` ([n_users + n_items, d]) that the entry's
+        padded rows stand for, as VIEWS where possible.  Rows past the end of the rank's block are whatever follows in
+        the table (or zeros past its end): they land in padding positions no column id refers to."""
+        out = []
+        n = table.shape[0]
+        for kind, sp, off in (("u", self.users, 0), ("i", self.items, self.n_users)):
+            for c in range(sp.n_chunks):
+                start = off + int(sp.cuts[rank]) + c * sp.cb
+                if start + sp.cb <= n:
+                    out.append(table[start:start + sp.cb])
+                else:
+                    head = table[min(start, n):n]
+                    out.append(torch.cat([head, table.new_zeros(sp.cb - head.shape[0], table.shape[1])], 0))
+        return out
 
     def nnz_per_rank(self, rows):
         owner_u = np.repeat(np.arange(self.P), np.diff(self.users.cuts))
@@ -162,7 +183,7 @@ def space_blocks(space, rows, cols, vals, rank, col_pos, n_cols, make_csr):
     mapped through `col_pos` into a padded space of `n_cols` positions (item-item graphs: both are the item space)."""
     rows = np.asarray(rows, dtype=np.int64)
     pr = space.pos[rows]
-    pc = col_pos[np.asarray(cols, dtype=np.int64)]
+    pc = np.asarray(cols, dtype=np.int64) if col_pos is None else col_pos[np.asarray(cols, dtype=np.int64)]   # None: as given
     vals = np.asarray(vals)
     out = []
     for c in range(space.n_chunks):
@@ -191,12 +212,13 @@ class RowShardedOp:
         when gather_acc else `out`.  Returns the list of pending collectives (call `.wait()` on each)."""
         works = []
         target = acc_out if gather_acc else out
-        for blk, lo, hi, rlo, rhi in self.entries:
+        for k, (blk, lo, hi, rlo, rhi) in enumerate(self.entries):
             ep = dict(scal)
             if Z is not None:
                 ep["Z"] = Z[lo:hi]
-            if acc_out is not None:
-                ep["acc_in"], ep["acc_out"] = acc_in[lo:hi], acc_out[lo:hi]
+            if acc_out is not None:      # acc_in: a padded tensor (sliced like `out`) or one [rows, d] tensor per entry
+                ep["acc_in"] = acc_in[k] if isinstance(acc_in, (list, tuple)) else acc_in[lo:hi]
+                ep["acc_out"] = acc_out[lo:hi]
             y = out[lo:hi] if write_y else None
             if ep:
                 self.local_spmm(blk, X, y, **ep)
@@ -228,6 +250,15 @@ class ShardedPropagator:
         blocks = ub + ib
         self.op = RowShardedOp([(blk,) + e[2:] for blk, e in zip(blocks, sharding.entries(rank))], local_spmm, group,
                                self.exchange)
+        self.entry_op = None     # set_entry_blocks: the same rows with NODE-order column ids (first layer of a model)
+
+    def set_entry_blocks(self, user_blocks, item_blocks):
+        """Blocks of the same rows whose column ids are node ids (BipartiteSharding.rank_blocks(node_cols=True)): the first
+        layer then multiplies the replicated node-order parameter table directly, without permuting it into the padded
+        space (sharded_lightgcn_mean(..., padded_out=True) uses them when present)."""
+        blocks = list(user_blocks) + list(item_blocks)
+        self.entry_op = RowShardedOp([(blk,) + e[2:] for blk, e in zip(blocks, self.sh.entries(self.rank))],
+                                     self.op.local_spmm, self.group, self.exchange)
 
     def layer(self, X, X_next):
         """X_next = A @ X for the full (padded) id space; returns X_next."""
@@ -250,46 +281,54 @@ class ShardedPropagator:
 class _ShardedLightGCNMean(torch.autograd.Function):
     """mean_l(A^l E0), l = 0..L, over the sharded rows: hip_ops._LightGCNMean with an all-gather after every layer.
     The layer sum rides in the SpMM epilogue on the rank's own rows; the LAST layer gathers the mean itself, so
-    forward and backward each move L all-gathers.  E0 and the result are replicated [N, d] tensors in node order
-    (every rank computes the same loss on them, so the incoming gradient is replicated too); per-row arithmetic is
-    the single-GPU kernel's: results are bit-identical to hip_ops.lightgcn_mean on the unsharded graph."""
+    forward and backward each move L all-gathers.  E0 is the replicated [N, d] table in node order (every rank computes
+    the same loss on the result, so the incoming gradient is replicated too); per-row arithmetic is the single-GPU
+    kernel's: results are bit-identical to hip_ops.lightgcn_mean on the unsharded graph.
+    padded_out=False: the result is in node order too (two permutations forward, two backward).
+    padded_out=True : the result stays in the PADDED space ([N_pad, d]: consumers gather rows through the position map,
+    `sharding.pos_tensor`); with the propagator's node-order entry blocks (`set_entry_blocks`) the first layer reads E0 as
+    it is, so the forward needs no permutation at all and the backward one (of the final gradient)."""
 
     @staticmethod
-    def forward(ctx, E0, prop, n_layers):
+    def forward(ctx, E0, prop, n_layers, padded_out):
         sh, L = prop.sh, int(n_layers)
-        ctx.prop, ctx.L = prop, L
+        ctx.prop, ctx.L, ctx.padded = prop, L, bool(padded_out)
+        E0 = E0.contiguous()
         if L == 0:
-            return E0.clone()
-        X0 = sh.pad(E0.contiguous())
-        acc = torch.zeros_like(X0)
-        bufs = [torch.empty_like(X0) if L > 1 else None, torch.empty_like(X0) if L > 2 else None]
+            return sh.pad(E0) if padded_out else E0.clone()
+        direct = padded_out and prop.entry_op is not None
+        X0 = E0 if direct else sh.pad(E0)
+        first_acc = sh.own_row_slices(E0, prop.rank) if direct else X0
+        acc = torch.zeros(sh.N_pad, E0.shape[1], dtype=E0.dtype, device=E0.device)
+        bufs = [torch.empty_like(acc) if L > 1 else None, torch.empty_like(acc) if L > 2 else None]
         cur = X0
         for layer in range(1, L + 1):
             last = layer == L
             nxt = acc if last else bufs[(layer - 1) % 2]
-            prop.op.run(cur, nxt, acc_in=X0 if layer == 1 else acc, acc_out=acc, gather_acc=last, write_y=not last,
-                        acc_scale=1.0 / (L + 1) if last else 1.0)
+            op = prop.entry_op if (direct and layer == 1) else prop.op
+            op.run(cur, nxt, acc_in=first_acc if layer == 1 else acc, acc_out=acc, gather_acc=last, write_y=not last,
+                   acc_scale=1.0 / (L + 1) if last else 1.0)
             cur = nxt
-        return sh.unpad_nodes(acc)
+        return acc if padded_out else sh.unpad_nodes(acc)
 
     @staticmethod
     def backward(ctx, dOut):
         prop, L, sh = ctx.prop, ctx.L, ctx.prop.sh
         if L == 0:
-            return dOut, None, None
+            return (sh.unpad_nodes(dOut) if ctx.padded else dOut), None, None, None
         s = 1.0 / (L + 1)
-        G = sh.pad(dOut.contiguous())
+        G = dOut.contiguous() if ctx.padded else sh.pad(dOut.contiguous())
         bufs = [torch.empty_like(G), torch.empty_like(G) if L > 1 else None]
         t = G
         for j in range(L):       # t <- s G + A^T t  (A symmetric; the first step also scales the inner term)
             out = bufs[j % 2]
             prop.op.run(t, out, Z=G, alpha=s if j == 0 else 1.0, beta=s)
             t = out
-        return sh.unpad_nodes(t), None, None
+        return sh.unpad_nodes(t), None, None, None
 
 
-def sharded_lightgcn_mean(prop: ShardedPropagator, E0, n_layers):
-    return _ShardedLightGCNMean.apply(E0, prop, n_layers)
+def sharded_lightgcn_mean(prop: ShardedPropagator, E0, n_layers, padded_out=False):
+    return _ShardedLightGCNMean.apply(E0, prop, n_layers, padded_out)
 
 
 class ShardedSquareMatrix:
@@ -304,7 +343,13 @@ class ShardedSquareMatrix:
                for c in range(space.n_chunks)]
         self.fwd = RowShardedOp([(b,) + e for b, e in zip(fwd_blocks, ent)], local_spmm, group, ex)
         self.bwd = RowShardedOp([(b,) + e for b, e in zip(bwd_blocks, ent)], local_spmm, group, ex)
+        self.fwd_node = None     # set_entry_blocks: rows of A with NODE-order column ids (X given in node order)
+        self._ent, self._ex = ent, ex
         self._pos_t = {}
+
+    def set_entry_blocks(self, fwd_blocks_node_cols):
+        self.fwd_node = RowShardedOp([(b,) + e for b, e in zip(fwd_blocks_node_cols, self._ent)], self.fwd.local_spmm,
+                                     self.fwd.group, self._ex)
 
     def pos_tensor(self, device):
         key = str(device)
@@ -346,6 +391,33 @@ class _ShardedSpMM(torch.autograd.Function):
 
 def sharded_spmm(mat: ShardedSquareMatrix, X, Z=None):
     return _ShardedSpMM.apply(X, Z, mat)
+
+
+class _ShardedSpMMPadded(torch.autograd.Function):
+    """A @ X + Zp with X in NODE order (read through the matrix's node-order-column entry blocks), Zp and the result in
+    the PADDED space of the matrix's row space: no permutation forward, one (of dX) backward."""
+
+    @staticmethod
+    def forward(ctx, X, Zp, mat):
+        ctx.mat = mat
+        out = torch.empty(mat.space.size, X.shape[1], dtype=X.dtype, device=X.device)
+        mat.fwd_node.run(X.contiguous(), out, Z=Zp.contiguous(), beta=1.0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dY):
+        mat = ctx.mat
+        dY = dY.contiguous()
+        dX = None
+        if ctx.needs_input_grad[0]:
+            out = torch.empty_like(dY)
+            mat.bwd.run(dY, out)
+            dX = mat.unpad(out)
+        return dX, (dY if ctx.needs_input_grad[1] else None), None
+
+
+def sharded_spmm_padded(mat: ShardedSquareMatrix, X, Zp):
+    return _ShardedSpMMPadded.apply(X, Zp, mat)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -257,6 +257,11 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
             np.stack([lr, pc]), vals, n_rows, n_cols, self.device)
         ub, ib = sh.rank_blocks(r, c, v, self.rank, make)
         self.norm_prop = ShardedPropagator(sh, ub, ib, self.rank, _local_spmm, group=self.group, force_collectives=self.force)
+        # the same rows with node-order column ids: the first layer reads the replicated parameter table as it is, and
+        # everything downstream of the propagation lives in the padded space (batch rows are gathered through pos_u / pos_i)
+        self.norm_prop.set_entry_blocks(*sh.rank_blocks(r, c, v, self.rank, make, node_cols=True))
+        self.pos_u = torch.from_numpy(sh.users.pos).to(self.device)
+        self.pos_i = torch.from_numpy(sh.items.pos - sh.U_pad).to(self.device)
         self.masked_prop = None
         rows = torch.from_numpy(self.interaction_matrix.row.astype(np.int64))
         cols = torch.from_numpy(self.interaction_matrix.col.astype(np.int64))
@@ -294,6 +299,7 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         bwd = space_blocks(sh.items, idx[1], idx[0], val, self.rank, ipos, sh.items.size, make_i)
         self.mm_adj = ShardedSquareMatrix(sh.items, fwd, bwd, self.rank, _local_spmm, group=self.group,
                                           force_collectives=self.force)
+        self.mm_adj.set_entry_blocks(space_blocks(sh.items, idx[0], idx[1], val, self.rank, None, ni, make_i))
         self.v_feat_dim = None if self.v_feat is None else self.v_feat.shape[1]
         # the full tables are only needed up to here (kNN graph + this rank's rows)
         if config['dist_keep_full_features'] is not True:
@@ -321,27 +327,38 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         rows, cols, vals = torch.cat((eu, ei + nu)), torch.cat((ei + nu, eu)), torch.cat((w, w))   # freedom.py:139-143
         pos = sh.pos_tensor(rows.device)
         pr, pc = pos[rows], pos[cols]
-        blocks = []
+        blocks, entry = [], []
         for _, _, lo, hi, _, _ in sh.entries(self.rank):
             sel = (pr >= lo) & (pr < hi)
-            blocks.append(hip_ops.CsrGraph.from_coo_device((pr[sel] - lo).to(torch.int32).contiguous(),
-                                                           pc[sel].to(torch.int32).contiguous(), vals[sel].contiguous(),
-                                                           hi - lo, sh.N_pad))
+            lr, vv = (pr[sel] - lo).to(torch.int32).contiguous(), vals[sel].contiguous()
+            blocks.append(hip_ops.CsrGraph.from_coo_device(lr, pc[sel].to(torch.int32).contiguous(), vv, hi - lo, sh.N_pad))
+            entry.append(hip_ops.CsrGraph.from_coo_device(lr, cols[sel].to(torch.int32).contiguous(), vv, hi - lo,
+                                                          self.n_nodes))
         nc = sh.n_chunks
         self.masked_prop = ShardedPropagator(sh, blocks[:nc], blocks[nc:], self.rank, _local_spmm, group=self.group,
                                              force_collectives=self.force)
+        self.masked_prop.set_entry_blocks(entry[:nc], entry[nc:])
 
-    def forward(self, prop):
-        from mmrec_amd.dist import sharded_lightgcn_mean, sharded_spmm
+    def forward_padded(self, prop):
+        """-> (user table [U_pad, d], item table [I_pad, d]) in the PADDED id space: row of user u = pos_u[u], of item i =
+        pos_i[i].  No permutation of the [N, d] tables on the way (the first layers read the node-order parameters through
+        node-order-column blocks); the backward permutes the two final gradients only."""
+        from mmrec_amd.dist import sharded_lightgcn_mean, sharded_spmm, sharded_spmm_padded
+        sh = self.sharding
         ego = torch.cat((self.user_embedding.weight, self.item_id_embedding.weight), dim=0)
-        mean = sharded_lightgcn_mean(prop, ego, self.n_ui_layers)
-        u_g, i_g = mean[:self.n_users], mean[self.n_users:]
+        mean = sharded_lightgcn_mean(prop, ego, self.n_ui_layers, padded_out=True)
+        u_p, i_gp = mean[:sh.U_pad], mean[sh.U_pad:]
         h = self.item_id_embedding.weight
         if self.n_layers == 0:
-            return u_g, i_g + h
+            return u_p, i_gp + self.mm_adj.pad(h)
         for _ in range(self.n_layers - 1):
             h = sharded_spmm(self.mm_adj, h)
-        return u_g, sharded_spmm(self.mm_adj, h, Z=i_g.contiguous())
+        return u_p, sharded_spmm_padded(self.mm_adj, h, i_gp)
+
+    def forward(self, prop):
+        """node-order (user_all [n_users, d], item_all [n_items, d]), like FREEDOM.forward"""
+        u_p, i_p = self.forward_padded(prop)
+        return u_p[self.pos_u], i_p[self.pos_i]
 
     def eval_embeddings(self):
         return self.forward(self.norm_prop)
@@ -360,9 +377,10 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
 
     def calculate_loss(self, interaction):
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
-        ua, ia = self.forward(self.masked_prop)
+        ua, ia = self.forward_padded(self.masked_prop)            # padded tables: batch rows through the position maps
         ua, ia = ua.contiguous(), ia.contiguous()
-        loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
+        users = self.pos_u[users]
+        loss = hip_ops.bpr_loss(ua, ia, users, self.pos_i[pos_items], self.pos_i[neg_items])
         rows = torch.cat((pos_items, neg_items))
         b = pos_items.shape[0]
         lp = torch.arange(b, device=rows.device)
