@@ -55,7 +55,11 @@ typedef __attribute__((ext_vector_type(16))) float acc16;
 
 constexpr int F_QWG = 256;     // queries per workgroup: 4 waves x 2 fragments x 32
 constexpr int F_CAPQ = 256;    // survivor slots per query over all ranges
-constexpr int F_MINR = 8, F_MAXR = 16;   // candidate ranges: 256..512 group maxima per query
+#ifndef MMREC_TF_MINR      // tools/prof_topk_ranges.py sweeps the number of candidate ranges
+#define MMREC_TF_MINR 8
+#define MMREC_TF_MAXR 16
+#endif
+constexpr int F_MINR = MMREC_TF_MINR, F_MAXR = MMREC_TF_MAXR;   // candidate ranges: 256..512 group maxima per query
 constexpr int F_SLOW_WAVES = 8;   // waves sharing one query of the slow queue
 constexpr int F_SLOW_MASK_LDS = 4096;   // mask entries of such a query staged in LDS
 constexpr int F_SLOW_PARTS = 4096;      // (query, split) partial top-k lists of the split slow path (2 MiB)
