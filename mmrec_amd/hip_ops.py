@@ -271,6 +271,34 @@ def lightgcn_mean(g: CsrGraph, E0, n_layers):
     return _LightGCNMean.apply(E0, g, n_layers)
 
 
+class _LightGCNMeanParts(torch.autograd.Function):
+    """_LightGCNMean on the row-wise concatenation of several tables (user table, item table), returning the mean split
+    back into the same row blocks.  The same launches; what goes away is autograd's bookkeeping around them at 1.5M rows:
+    the zero-filled [N, 64] gradients of the two output slices and their sum, and the split of the cat's gradient."""
+
+    @staticmethod
+    def forward(ctx, g, n_layers, *parts):
+        ctx.sizes = [p.shape[0] for p in parts]
+        E0 = torch.cat([p.detach() for p in parts], dim=0)
+        ctx.g, ctx.L = g, int(n_layers)
+        out = _LightGCNMean.forward(ctx, E0, g, n_layers)
+        return tuple(out.split(ctx.sizes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        like = next(x for x in grads if x is not None)
+        dOut = torch.empty((sum(ctx.sizes), like.shape[1]), dtype=like.dtype, device=like.device)
+        for dst, src in zip(dOut.split(ctx.sizes), grads):
+            dst.zero_() if src is None else dst.copy_(src)
+        t = _LightGCNMean.backward(ctx, dOut)[0]
+        return (None, None) + tuple(t.split(ctx.sizes))
+
+
+def lightgcn_mean_parts(g: CsrGraph, parts, n_layers):
+    """mean_l(A^l cat(parts)) as a tuple of row blocks, one per input table (freedom.py:165-178: cat, propagate, split)"""
+    return _LightGCNMeanParts.apply(g, n_layers, *parts)
+
+
 class _LayerGCNSum(torch.autograd.Function):
     """sum_l w_l * (A E_{l-1}),  w_l = cos(A E_{l-1}, E0) per row, E_l = w_l * A E_{l-1}
     (layergcn.py:125-138).  SpMM kernel + fused cos-scale/accumulate kernel per layer."""
@@ -360,6 +388,66 @@ class _BprLoss(torch.autograd.Function):
                                          users.numel(), U.shape[1], _p(coef), _p(g), ctx.scale, _p(dU),
                                          _p(dI), _p(dI), _stream()), "bpr_bwd")
         return dU, dI, None, None, None, None, None
+
+
+class _BprLossShared(torch.autograd.Function):
+    """Several BPR terms over the SAME user rows U[users] (FREEDOM's id term and its two modality terms,
+    freedom.py:197-211), one loss scalar per term.  The same forward / backward kernels as _BprLoss, but ONE dense
+    gradient buffer for U that the backward launches accumulate into, instead of one zero-filled [n_users, d] buffer per
+    term and their sums."""
+
+    @staticmethod
+    def forward(ctx, U, users, variant, scale, n_terms, *flat):
+        lib = _lib.load()
+        U = _chk(U.contiguous(), torch.float32, "U", 2)
+        _chk(users, torch.int64, "users", 1)
+        B, dev = users.numel(), U.device
+        tables, ids, coefs, losses = [], [], [], []
+        ws = _ws(lib.mmrec_bpr_workspace_bytes(B), dev)
+        for t in range(n_terms):
+            I, pos, neg = flat[3 * t], flat[3 * t + 1], flat[3 * t + 2]
+            I = _chk(I.contiguous(), torch.float32, "I", 2)
+            _chk(pos, torch.int64, "pos", 1), _chk(neg, torch.int64, "neg", 1)
+            if U.shape[1] != I.shape[1] or U.shape[1] % EMB_DIM:
+                raise _lib.MMRecHipError("U and I need the same row width, a multiple of %d" % EMB_DIM)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            coef = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+            _lib.check(lib.mmrec_bpr_fwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), B, U.shape[1],
+                                             int(variant), float(scale), _p(loss), _p(coef), _p(ws), _stream()), "bpr_fwd")
+            tables.append(I), ids.extend((pos, neg)), coefs.append(coef), losses.append(loss)
+        ctx.save_for_backward(U, users, *tables, *ids, *coefs)
+        ctx.scale, ctx.n_terms = float(scale), n_terms
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.load()
+        n = ctx.n_terms
+        saved = ctx.saved_tensors
+        U, users = saved[0], saved[1]
+        tables, ids, coefs = saved[2:2 + n], saved[2 + n:2 + 3 * n], saved[2 + 3 * n:]
+        dU = torch.zeros_like(U) if ctx.needs_input_grad[0] else None
+        out = []
+        for t in range(n):
+            I, pos, neg = tables[t], ids[2 * t], ids[2 * t + 1]
+            need_i = ctx.needs_input_grad[5 + 3 * t]
+            if gs[t] is None or (dU is None and not need_i):
+                out.extend((torch.zeros_like(I) if need_i else None, None, None))
+                continue
+            dI = torch.zeros_like(I) if need_i else None
+            g = gs[t].contiguous().to(torch.float32)
+            _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), users.numel(), U.shape[1],
+                                             _p(coefs[t]), _p(g), ctx.scale, _p(dU), _p(dI), _p(dI), _stream()), "bpr_bwd")
+            out.extend((dI, None, None))
+        return (dU, None, None, None, None) + tuple(out)
+
+
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean"):
+    """[bpr_loss(U, I_t, users, pos_t, neg_t) for (I_t, pos_t, neg_t) in terms] with one shared gradient buffer for U"""
+    B = users.numel()
+    scale = 1.0 / max(B, 1) if reduction == "mean" else 1.0
+    flat = [x for term in terms for x in term]
+    return _BprLossShared.apply(U, users, variant, scale, len(terms), *flat)
 
 
 def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):

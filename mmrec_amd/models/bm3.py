@@ -59,9 +59,9 @@ class BM3(FusedEvalMixin, GeneralRecommender):
             nn.init.xavier_normal_(self.text_trs.weight)
 
     def forward(self):
-        ego = torch.cat((self.user_embedding.weight, self.item_id_embedding.weight), dim=0)
-        mean = hip_ops.lightgcn_mean(self.norm_adj, ego, self.n_layers)
-        return mean[:self.n_users], mean[self.n_users:] + self.item_id_embedding.weight
+        u, i = hip_ops.lightgcn_mean_parts(self.norm_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
+                                           self.n_layers)
+        return u, i + self.item_id_embedding.weight
 
     def _predict(self, x):
         return hip_ops.linear(x, self.predictor.weight, self.predictor.bias)

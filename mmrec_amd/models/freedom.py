@@ -124,9 +124,8 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
                                                              self.n_users, self.n_items)
 
     def forward(self, adj):
-        ego = torch.cat((self.user_embedding.weight, self.item_id_embedding.weight), dim=0)
-        mean = hip_ops.lightgcn_mean(adj, ego, self.n_ui_layers)
-        u_g, i_g = mean[:self.n_users], mean[self.n_users:]
+        # cat -> propagate -> split (freedom.py:165-178) in one autograd node: no zero-padded slice gradients
+        u_g, i_g = hip_ops.lightgcn_mean_parts(adj, (self.user_embedding.weight, self.item_id_embedding.weight), self.n_ui_layers)
         h = self.item_id_embedding.weight
         if self.n_layers == 0:
             return u_g, i_g + h
@@ -148,8 +147,6 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
                         emb.prefetch(rows)
         ua, ia = self.forward(self.masked_adj)
         self.build_item_graph = False
-        loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
-        mf_t = mf_v = 0.0
         if self.lazy_projection:
             # The reference projects ALL items every batch (freedom.py:205,208) but only the pos/neg rows
             # are ever consumed (:206,:209).  A projection row depends on its own
@@ -160,13 +157,14 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
             lp = torch.arange(b, device=rows.device)
             ln = lp + b
             gather = (lambda emb: emb.rows(rows)) if self.lazy_feature_adam else (lambda emb: emb.weight[rows])
+            terms = [(ia, pos_items, neg_items)]
             if self.t_feat is not None:
-                tf = hip_ops.linear(gather(self.text_embedding), self.text_trs.weight, self.text_trs.bias)
-                mf_t = hip_ops.bpr_loss(ua, tf, users, lp, ln)
+                terms.append((hip_ops.linear(gather(self.text_embedding), self.text_trs.weight, self.text_trs.bias), lp, ln))
             if self.v_feat is not None:
-                vf = hip_ops.linear(gather(self.image_embedding), self.image_trs.weight, self.image_trs.bias)
-                mf_v = hip_ops.bpr_loss(ua, vf, users, lp, ln)
-            return loss + self.reg_weight * (mf_t + mf_v)
+                terms.append((hip_ops.linear(gather(self.image_embedding), self.image_trs.weight, self.image_trs.bias), lp, ln))
+            return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms), self.t_feat is not None, self.reg_weight)
+        loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
+        mf_t = mf_v = 0.0
         if self.t_feat is not None:
             text_feats = hip_ops.linear(self.text_embedding.weight, self.text_trs.weight, self.text_trs.bias)
             mf_t = hip_ops.bpr_loss(ua, text_feats, users, pos_items, neg_items)
@@ -174,6 +172,17 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
             image_feats = hip_ops.linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
             mf_v = hip_ops.bpr_loss(ua, image_feats, users, pos_items, neg_items)
         return loss + self.reg_weight * (mf_t + mf_v)
+
+
+def _combine(losses, has_text, reg_weight):
+    """bpr + reg_weight * (mf_t + mf_v), in the reference's order of operations (freedom.py:211)"""
+    mf = [0.0, 0.0]
+    rest = list(losses[1:])
+    if has_text:
+        mf[0] = rest.pop(0)
+    if rest:
+        mf[1] = rest.pop(0)
+    return losses[0] + reg_weight * (mf[0] + mf[1])
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -380,17 +389,16 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         ua, ia = self.forward_padded(self.masked_prop)            # padded tables: batch rows through the position maps
         ua, ia = ua.contiguous(), ia.contiguous()
         users = self.pos_u[users]
-        loss = hip_ops.bpr_loss(ua, ia, users, self.pos_i[pos_items], self.pos_i[neg_items])
         rows = torch.cat((pos_items, neg_items))
         b = pos_items.shape[0]
         lp = torch.arange(b, device=rows.device)
         ln = lp + b
-        mf_t = mf_v = 0.0
+        terms = [(ia, self.pos_i[pos_items], self.pos_i[neg_items])]
         if self.t_feat is not None:
-            mf_t = hip_ops.bpr_loss(ua, self._owned_projection(self.text_embedding, self.text_trs, rows), users, lp, ln)
+            terms.append((self._owned_projection(self.text_embedding, self.text_trs, rows), lp, ln))
         if self.v_feat is not None:
-            mf_v = hip_ops.bpr_loss(ua, self._owned_projection(self.image_embedding, self.image_trs, rows), users, lp, ln)
-        return loss + self.reg_weight * (mf_t + mf_v)
+            terms.append((self._owned_projection(self.image_embedding, self.image_trs, rows), lp, ln))
+        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms), self.t_feat is not None, self.reg_weight)
 
     @torch.no_grad()
     def full_sort_topk(self, interaction, k):

@@ -32,8 +32,8 @@ class LightGCN(FusedEvalMixin, GeneralRecommender):
         return torch.cat([self.embedding_dict['user_emb'], self.embedding_dict['item_emb']], 0)
 
     def forward(self):
-        out = hip_ops.lightgcn_mean(self.norm_adj_matrix, self.get_ego_embeddings(), self.n_layers)
-        return out[:self.n_users], out[self.n_users:]
+        return hip_ops.lightgcn_mean_parts(self.norm_adj_matrix, (self.embedding_dict['user_emb'],
+                                                                  self.embedding_dict['item_emb']), self.n_layers)
 
     eval_embeddings = forward
 

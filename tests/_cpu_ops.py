@@ -127,6 +127,11 @@ def lightgcn_mean(g, E0, n_layers):
     return torch.stack(outs, 1).mean(1)
 
 
+def lightgcn_mean_parts(g, parts, n_layers):
+    sizes = [p.shape[0] for p in parts]
+    return tuple(lightgcn_mean(g, torch.cat(list(parts), dim=0), n_layers).split(sizes))
+
+
 def layergcn_sum(g, E0, n_layers):
     _spmm_args(g, E0)
     _mat(E0, "E0", width=EMB_DIM)
@@ -148,6 +153,10 @@ def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):
     if users.numel() == 0:
         return per.sum()
     return per.mean() if reduction == "mean" else per.sum()
+
+
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean"):
+    return tuple(bpr_loss(U, I, users, pos, neg, variant, reduction) for I, pos, neg in terms)
 
 
 def infonce(E1, E2, ids, tau):
@@ -229,7 +238,8 @@ def spmm_vals(dyn, X, vals):
     return out.index_add(0, dyn.rows, vals.unsqueeze(1) * X[dyn.cols])
 
 
-_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "lightgcn_mean", "layergcn_sum", "bpr_loss", "infonce",
+_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "lightgcn_mean", "lightgcn_mean_parts", "layergcn_sum", "bpr_loss",
+            "bpr_losses_shared_users", "infonce",
             "gather_sqnorm", "cosine_mean", "linear", "score_topk", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 

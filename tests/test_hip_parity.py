@@ -218,6 +218,65 @@ def test_bpr_variants_with_duplicates(ops, dev, variant, reduction):
     close(Id.grad, I.grad, atol=1e-6)
 
 
+def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden):
+    """FREEDOM's fused autograd nodes (one [n_users, d] gradient buffer for the three BPR terms; cat -> propagate -> split
+    as one node) against the per-op composition with torch's cat / slices / adds around it and against the CPU oracle:
+    identical forward values, gradients within rounding of the changed summation order, an unused output handled."""
+    g = golden
+    graph = golden_graph(ops, g, dev)
+    nu = int(g["n_users"])
+    gen = torch.Generator().manual_seed(11)
+    B = 233
+    b = D(g["batch"], dev)[:, :B].contiguous()
+    lp = torch.arange(B // 3, device=dev).repeat(3)[:B].contiguous()     # duplicate slots on purpose
+    ln = (lp + 17).contiguous()
+    T = torch.randn(400, 64, generator=gen) * 0.3
+    V = torch.randn(400, 64, generator=gen) * 0.3
+
+    def run(fused):
+        ue, ie = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
+        t, v = T.to(dev).requires_grad_(), V.to(dev).requires_grad_()
+        if fused:
+            u, i = ops.lightgcn_mean_parts(graph, (ue, ie), 2)
+            l0, lt, lv = ops.bpr_losses_shared_users(u, b[0], [(i, b[1], b[2]), (t, lp, ln), (v, lp, ln)])
+        else:
+            out = ops.lightgcn_mean(graph, torch.cat([ue, ie], 0), 2)
+            u, i = out[:nu].contiguous(), out[nu:].contiguous()
+            l0, lt, lv = (ops.bpr_loss(u, i, b[0], b[1], b[2]), ops.bpr_loss(u, t, b[0], lp, ln),
+                          ops.bpr_loss(u, v, b[0], lp, ln))
+        loss = l0 + 0.37 * (lt + lv)
+        loss.backward()
+        return [x.detach().cpu() for x in (loss, u, i, ue.grad, ie.grad, t.grad, v.grad)]
+    a, r = run(True), run(False)
+    for x, y in zip(a[:3], r[:3]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[3:], r[3:]):
+        close(x, y, atol=1e-7, rtol=1e-5)
+    # CPU oracle for the same composite (lightgcn.py:115-128 + freedom.py:180-187 restated)
+    n = graph.n_rows
+    adj = orc.sparse_coo(g["norm_adj_idx"], g["norm_adj_val"], n)
+    ue, ie = torch.tensor(g["lgn_user_emb"], requires_grad=True), torch.tensor(g["lgn_item_emb"], requires_grad=True)
+    t, v = T.clone().requires_grad_(), V.clone().requires_grad_()
+    u, i = orc.lightgcn_forward(adj, ue, ie, 2)
+    bc, lpc, lnc = b.cpu(), lp.cpu(), ln.cpu()
+    ref = (orc.bpr_logsigmoid(u[bc[0]], i[bc[1]], i[bc[2]]) +
+           0.37 * (orc.bpr_logsigmoid(u[bc[0]], t[lpc], t[lnc]) + orc.bpr_logsigmoid(u[bc[0]], v[lpc], v[lnc])))
+    ref.backward()
+    close(a[0], ref, rtol=1e-5)
+    for x, y in zip(a[3:], (ue.grad, ie.grad, t.grad, v.grad)):
+        close(x, y, atol=1e-7, rtol=1e-4)
+    # an output nobody uses: its gradient slot arrives as None
+    ue, ie = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
+    u, i = ops.lightgcn_mean_parts(graph, (ue, ie), 2)
+    u.square().sum().backward()
+    ue2, ie2 = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
+    ops.lightgcn_mean(graph, torch.cat([ue2, ie2], 0), 2)[:nu].square().sum().backward()
+    close(ue.grad, ue2.grad.cpu(), atol=1e-7, rtol=1e-5)
+    close(ie.grad, ie2.grad.cpu(), atol=1e-7, rtol=1e-5)
+    l = ops.bpr_losses_shared_users(u.detach().requires_grad_(), b[0], [(i.detach(), b[1], b[2]), (T.to(dev), lp, ln)])
+    l[1].backward()                                                      # only the second term is used
+
+
 def test_bpr_extreme_scores(ops, dev):
     """logsigmoid / log(1e-10+sigmoid) differ for x << 0: both exact."""
     U = torch.zeros(4, 64)
