@@ -271,6 +271,19 @@ def lightgcn_mean(g: CsrGraph, E0, n_layers):
     return _LightGCNMean.apply(E0, g, n_layers)
 
 
+def row_blocks_of_one_buffer(ts):
+    """True if the tensors are consecutive contiguous row blocks of ONE allocation, i.e. their cat already exists"""
+    if any(t is None or not t.is_contiguous() or t.dtype != ts[0].dtype for t in ts):
+        return False
+    base = ts[0].untyped_storage().data_ptr()
+    end = ts[0].data_ptr()
+    for t in ts:
+        if t.untyped_storage().data_ptr() != base or t.data_ptr() != end:
+            return False
+        end += t.numel() * t.element_size()
+    return end <= base + ts[0].untyped_storage().nbytes()
+
+
 class _LightGCNMeanParts(torch.autograd.Function):
     """_LightGCNMean on the row-wise concatenation of several tables (user table, item table), returning the mean split
     back into the same row blocks.  The same launches; what goes away is autograd's bookkeeping around them at 1.5M rows:
@@ -279,7 +292,10 @@ class _LightGCNMeanParts(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, n_layers, *parts):
         ctx.sizes = [p.shape[0] for p in parts]
-        E0 = torch.cat([p.detach() for p in parts], dim=0)
+        if row_blocks_of_one_buffer(parts):        # models/_base.py AdjacentTablesMixin: the cat already exists
+            E0 = parts[0].detach().as_strided((sum(ctx.sizes), parts[0].shape[1]), (parts[0].shape[1], 1))
+        else:
+            E0 = torch.cat([p.detach() for p in parts], dim=0)
         ctx.g, ctx.L = g, int(n_layers)
         out = _LightGCNMean.forward(ctx, E0, g, n_layers)
         return tuple(out.split(ctx.sizes))
@@ -287,9 +303,13 @@ class _LightGCNMeanParts(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         like = next(x for x in grads if x is not None)
-        dOut = torch.empty((sum(ctx.sizes), like.shape[1]), dtype=like.dtype, device=like.device)
-        for dst, src in zip(dOut.split(ctx.sizes), grads):
-            dst.zero_() if src is None else dst.copy_(src)
+        n, d = sum(ctx.sizes), like.shape[1]
+        if row_blocks_of_one_buffer(grads):       # e.g. bpr_losses_shared_users(joint_grad=True): already laid out as cat(grads)
+            dOut = grads[0].as_strided((n, d), (d, 1))
+        else:
+            dOut = torch.empty((n, d), dtype=like.dtype, device=like.device)
+            for dst, src in zip(dOut.split(ctx.sizes), grads):
+                dst.zero_() if src is None else dst.copy_(src)
         t = _LightGCNMean.backward(ctx, dOut)[0]
         return (None, None) + tuple(t.split(ctx.sizes))
 
@@ -397,8 +417,9 @@ class _BprLossShared(torch.autograd.Function):
     term and their sums."""
 
     @staticmethod
-    def forward(ctx, U, users, variant, scale, n_terms, *flat):
+    def forward(ctx, U, users, variant, scale, n_terms, joint, *flat):
         lib = _lib.load()
+        ctx.joint = bool(joint)
         U = _chk(U.contiguous(), torch.float32, "U", 2)
         _chk(users, torch.int64, "users", 1)
         B, dev = users.numel(), U.device
@@ -426,28 +447,37 @@ class _BprLossShared(torch.autograd.Function):
         saved = ctx.saved_tensors
         U, users = saved[0], saved[1]
         tables, ids, coefs = saved[2:2 + n], saved[2 + n:2 + 3 * n], saved[2 + 3 * n:]
-        dU = torch.zeros_like(U) if ctx.needs_input_grad[0] else None
+        dU = dI0 = None
+        if ctx.joint and ctx.needs_input_grad[0] and ctx.needs_input_grad[6]:
+            # the gradients of U and of the first item table as adjacent row blocks of one zero-filled buffer: when both
+            # came out of lightgcn_mean_parts, its backward takes the buffer as the gradient of its output, copy-free
+            both = torch.zeros((U.shape[0] + tables[0].shape[0], U.shape[1]), dtype=U.dtype, device=U.device)
+            dU, dI0 = both[:U.shape[0]], both[U.shape[0]:]
+        elif ctx.needs_input_grad[0]:
+            dU = torch.zeros_like(U)
         out = []
         for t in range(n):
             I, pos, neg = tables[t], ids[2 * t], ids[2 * t + 1]
-            need_i = ctx.needs_input_grad[5 + 3 * t]
+            need_i = ctx.needs_input_grad[6 + 3 * t]
+            own = dI0 if t == 0 and dI0 is not None else None
             if gs[t] is None or (dU is None and not need_i):
-                out.extend((torch.zeros_like(I) if need_i else None, None, None))
+                out.extend(((own if own is not None else torch.zeros_like(I)) if need_i else None, None, None))
                 continue
-            dI = torch.zeros_like(I) if need_i else None
+            dI = (own if own is not None else torch.zeros_like(I)) if need_i else None
             g = gs[t].contiguous().to(torch.float32)
             _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), users.numel(), U.shape[1],
                                              _p(coefs[t]), _p(g), ctx.scale, _p(dU), _p(dI), _p(dI), _stream()), "bpr_bwd")
             out.extend((dI, None, None))
-        return (dU, None, None, None, None) + tuple(out)
+        return (dU, None, None, None, None, None) + tuple(out)
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean"):
-    """[bpr_loss(U, I_t, users, pos_t, neg_t) for (I_t, pos_t, neg_t) in terms] with one shared gradient buffer for U"""
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False):
+    """[bpr_loss(U, I_t, users, pos_t, neg_t) for (I_t, pos_t, neg_t) in terms] with one shared gradient buffer for U;
+    joint_grad: the gradient of the FIRST term's table is the row block right after U's in the same buffer"""
     B = users.numel()
     scale = 1.0 / max(B, 1) if reduction == "mean" else 1.0
     flat = [x for term in terms for x in term]
-    return _BprLossShared.apply(U, users, variant, scale, len(terms), *flat)
+    return _BprLossShared.apply(U, users, variant, scale, len(terms), joint_grad, *flat)
 
 
 def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):

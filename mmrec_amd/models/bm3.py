@@ -18,11 +18,13 @@ import torch.nn.functional as F
 from mmrec_amd import hip_ops
 from mmrec_amd.common.lazy_rows import LazyRowEmbedding, lazy_adam_enabled
 from mmrec_amd.graph import norm_adj_graph
-from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender
 
 
-class BM3(FusedEvalMixin, GeneralRecommender):
+class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
+    adjacent_tables = ('user_embedding.weight', 'item_id_embedding.weight')
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)

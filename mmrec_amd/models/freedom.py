@@ -19,7 +19,7 @@ import torch.nn as nn
 from mmrec_amd import hip_ops
 from mmrec_amd.common.lazy_rows import LazyRowEmbedding, lazy_adam_enabled
 from mmrec_amd.graph import knn_normalized_coo, mask_to_csr_device, norm_adj_graph, sparse_coo_to_graph
-from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender
 
 
 def build_mm_adj(v_feat, t_feat, knn_k, mm_image_weight, n_items):
@@ -54,8 +54,10 @@ def load_or_build_mm_adj(config, v_feat, t_feat, knn_k, mm_image_weight, n_items
     return g
 
 
-class FREEDOM(FusedEvalMixin, GeneralRecommender):
+class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
+    adjacent_tables = ('user_embedding.weight', 'item_id_embedding.weight')
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -162,7 +164,7 @@ class FREEDOM(FusedEvalMixin, GeneralRecommender):
                 terms.append((hip_ops.linear(gather(self.text_embedding), self.text_trs.weight, self.text_trs.bias), lp, ln))
             if self.v_feat is not None:
                 terms.append((hip_ops.linear(gather(self.image_embedding), self.image_trs.weight, self.image_trs.bias), lp, ln))
-            return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms), self.t_feat is not None, self.reg_weight)
+            return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, joint_grad=True), self.t_feat is not None, self.reg_weight)
         loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
         mf_t = mf_v = 0.0
         if self.t_feat is not None:
@@ -398,7 +400,7 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
             terms.append((self._owned_projection(self.text_embedding, self.text_trs, rows), lp, ln))
         if self.v_feat is not None:
             terms.append((self._owned_projection(self.image_embedding, self.image_trs, rows), lp, ln))
-        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms), self.t_feat is not None, self.reg_weight)
+        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, joint_grad=True), self.t_feat is not None, self.reg_weight)
 
     @torch.no_grad()
     def full_sort_topk(self, interaction, k):

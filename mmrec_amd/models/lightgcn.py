@@ -10,11 +10,13 @@ import torch.nn as nn
 
 from mmrec_amd import hip_ops
 from mmrec_amd.graph import norm_adj_graph
-from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender, emb_loss_rows
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, emb_loss_rows
 
 
-class LightGCN(FusedEvalMixin, GeneralRecommender):
+class LightGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+
+    adjacent_tables = ('embedding_dict.user_emb', 'embedding_dict.item_emb')
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)

@@ -155,7 +155,7 @@ def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):
     return per.mean() if reduction == "mean" else per.sum()
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean"):
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False):
     return tuple(bpr_loss(U, I, users, pos, neg, variant, reduction) for I, pos, neg in terms)
 
 

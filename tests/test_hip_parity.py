@@ -228,17 +228,17 @@ def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden)
     gen = torch.Generator().manual_seed(11)
     B = 233
     b = D(g["batch"], dev)[:, :B].contiguous()
-    lp = torch.arange(B // 3, device=dev).repeat(3)[:B].contiguous()     # duplicate slots on purpose
+    lp = (torch.arange(B, device=dev) % 77).contiguous()                 # duplicate slots on purpose
     ln = (lp + 17).contiguous()
     T = torch.randn(400, 64, generator=gen) * 0.3
     V = torch.randn(400, 64, generator=gen) * 0.3
 
-    def run(fused):
+    def run(fused, joint=False):
         ue, ie = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
         t, v = T.to(dev).requires_grad_(), V.to(dev).requires_grad_()
         if fused:
             u, i = ops.lightgcn_mean_parts(graph, (ue, ie), 2)
-            l0, lt, lv = ops.bpr_losses_shared_users(u, b[0], [(i, b[1], b[2]), (t, lp, ln), (v, lp, ln)])
+            l0, lt, lv = ops.bpr_losses_shared_users(u, b[0], [(i, b[1], b[2]), (t, lp, ln), (v, lp, ln)], joint_grad=joint)
         else:
             out = ops.lightgcn_mean(graph, torch.cat([ue, ie], 0), 2)
             u, i = out[:nu].contiguous(), out[nu:].contiguous()
@@ -247,7 +247,9 @@ def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden)
         loss = l0 + 0.37 * (lt + lv)
         loss.backward()
         return [x.detach().cpu() for x in (loss, u, i, ue.grad, ie.grad, t.grad, v.grad)]
-    a, r = run(True), run(False)
+    a, r, j = run(True), run(False), run(True, True)
+    for k, (x, y) in enumerate(zip(a, j)):                               # the copy-free gradient hand-over changes nothing
+        assert torch.equal(x, y) if k < 3 else torch.allclose(x, y, rtol=1e-5, atol=1e-7)   # (atomics: last-ulp order)
     for x, y in zip(a[:3], r[:3]):
         assert torch.equal(x, y)
     for x, y in zip(a[3:], r[3:]):
@@ -265,6 +267,19 @@ def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden)
     close(a[0], ref, rtol=1e-5)
     for x, y in zip(a[3:], (ue.grad, ie.grad, t.grad, v.grad)):
         close(x, y, atol=1e-7, rtol=1e-4)
+    # the two tables as adjacent row blocks of one allocation (models/_base.py AdjacentTablesMixin): no cat, same numbers
+    both = torch.cat([D(g["lgn_user_emb"], dev), D(g["lgn_item_emb"], dev)], 0)
+    ue, ie = both[:nu].detach().requires_grad_(), both[nu:].detach().requires_grad_()
+    assert ops.row_blocks_of_one_buffer((ue, ie)) and not ops.row_blocks_of_one_buffer((ie, ue))
+    u, i = ops.lightgcn_mean_parts(graph, (ue, ie), 2)
+    l0, = ops.bpr_losses_shared_users(u, b[0], [(i, b[1], b[2])], joint_grad=True)
+    l0.backward()
+    assert torch.equal(u.detach().cpu(), a[1]) and torch.equal(i.detach().cpu(), a[2])
+    ue2, ie2 = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
+    out = ops.lightgcn_mean(graph, torch.cat([ue2, ie2], 0), 2)
+    ops.bpr_loss(out[:nu].contiguous(), out[nu:].contiguous(), b[0], b[1], b[2]).backward()
+    close(ue.grad, ue2.grad, atol=1e-7, rtol=1e-5)
+    close(ie.grad, ie2.grad, atol=1e-7, rtol=1e-5)
     # an output nobody uses: its gradient slot arrives as None
     ue, ie = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
     u, i = ops.lightgcn_mean_parts(graph, (ue, ie), 2)

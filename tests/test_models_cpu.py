@@ -184,3 +184,29 @@ def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     sizes.clear()
     res = t2.evaluate(valid_data)
     assert sizes and res["recall@5"] == whole["recall@5"] and "recall@70" in res
+
+
+def test_adjacent_id_tables_layout(tmp_path, golden):
+    """AdjacentTablesMixin: after `.to(...)` the user / item id tables are consecutive row blocks of one allocation (the
+    forward's cat exists already); names, shapes, values and Parameter-ness unchanged, a state_dict loads in place, and
+    the model computes the same loss as with separately allocated tables."""
+    import torch
+    from mmrec_amd import hip_ops
+    from mmrec_amd.utils.utils import get_model
+    config, train_data, _ = G.setup(tmp_path, golden, "FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3}, use_gpu=False)
+    model = get_model("FREEDOM")(config, train_data)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    assert not hip_ops.row_blocks_of_one_buffer((model.user_embedding.weight, model.item_id_embedding.weight))
+    model.set_kept_edges(torch.as_tensor(golden["fr_keep_idx"]))
+    batch = G.batch_of(golden, torch.device("cpu"))
+    l0 = float(model.calculate_loss(batch))
+    model = model.to("cpu")
+    ps = (model.user_embedding.weight, model.item_id_embedding.weight)
+    assert hip_ops.row_blocks_of_one_buffer(ps) and all(isinstance(p, torch.nn.Parameter) and p.requires_grad for p in ps)
+    assert [k for k in model.state_dict()] == list(before)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert float(model.calculate_loss(batch)) == l0
+    model.load_state_dict({k: v + 1 if k == "user_embedding.weight" else v for k, v in before.items()})
+    assert hip_ops.row_blocks_of_one_buffer((model.user_embedding.weight, model.item_id_embedding.weight))
+    assert torch.equal(model.user_embedding.weight.detach(), before["user_embedding.weight"] + 1)
