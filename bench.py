@@ -34,6 +34,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -611,13 +612,38 @@ def main():
     timed = True
     dt = timed_steps(step, args.steps)
     timed = False
+    state = {"dist_extra": None, "c5_eval": None, "done": False}
+    timed_events = list(ev)
+
+    def emit():
+        emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total, dt, timed_events, state)
+    watchdog = None
+    if multi:
+        # the headline is measured; the companions below run collectives this container could only exercise on a
+        # one-rank group and gloo.  A rank stuck in one of them must not cost the line: after the budget every rank's
+        # watchdog emits what exists (rank 0 prints) and ends the process
+        budget = float(os.environ.get("MMREC_BENCH_COMPANION_BUDGET_S", "420"))
+
+        def give_up():
+            if state["done"]:
+                return
+            state["done"] = True
+            log("companions exceeded %.0f s: emitting the headline without them" % budget)
+            try:
+                state["dist_extra"] = dict(state["dist_extra"] or {}, companions="stopped after %.0f s" % budget)
+                emit()
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(budget, give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     # N > 1: what the exchange costs and how much of it hides under the SpMMs (allgather layout), the nnz balance
     # of the cut, the no-exchange alternative (one full replica per GPU), a weak-scaling companion and a sharded
     # training step -- all AFTER the timed region
     dist_extra = None
     if multi:
-        dist_extra = {}
+        dist_extra = state["dist_extra"] = {}
         if args.layout == "allgather":
             per_rank = sh.nnz_per_rank(r)
             dist_extra["nnz_per_rank"] = [int(x) for x in per_rank]
@@ -705,7 +731,20 @@ def main():
         del Ue, Ie
     except Exception as ex:
         c5_eval = {"error": repr(ex)}
+    state["c5_eval"] = c5_eval
+    if watchdog is not None:
+        watchdog.cancel()
+    if not state["done"]:
+        state["done"] = True
+        emit()
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total, dt, ev, state):
+    """rank 0: the ONE JSON line (headline + roofline + companions gathered so far)"""
+    dist_extra, c5_eval = state["dist_extra"], state["c5_eval"]
     # roofline of the dominant kernel family (one SpMM call), from the events of this rank
     call_ms = np.array([s.elapsed_time(e) for s, e, _, _ in ev])
     call_alg = np.array([alg_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
@@ -766,9 +805,6 @@ def main():
             line["extra"] = dist_extra
         line.setdefault("extra", {})["c5_full_eval"] = c5_eval
         print(json.dumps(line), flush=True)
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
