@@ -242,7 +242,9 @@ def c5_full_eval(dev, rank, world, user_emb, item_emb, eu, ei, n_users, barrier)
     """The second half of BASELINE.json's metric at config-5 size: full-sort evaluation of ALL 1M users against the 500K
     items (train positives masked, top-50), users sharded over the ranks, item table replicated -- no exchange in the data
     path (SURVEY.md 8e "P5 eval: shard users"), so it scales with the GPU count.  Every rank ranks its slice in blocks of
-    20,000 users (the [20,000, 500,000] score block is never formed); users/s = all users / max-over-ranks time."""
+    50,000 users (the [50,000, 500,000] score block is never formed; the candidate-side preparation of a call -- column
+    means, fp16 copy of the item table -- is per call, 0.56 ms: 17 % of a 20,000-user block); users/s = all users /
+    max-over-ranks time."""
     from mmrec_amd import hip_ops
     per = -(-n_users // world)
     lo, hi = min(rank * per, n_users), min((rank + 1) * per, n_users)
@@ -250,8 +252,8 @@ def c5_full_eval(dev, rank, world, user_emb, item_emb, eu, ei, n_users, barrier)
     rp, col = hip_ops.mask_to_csr(np.stack([eu[s:e] - lo, ei[s:e]]), max(hi - lo, 1), dev)
     rp_host = rp.cpu().numpy().astype(np.int64)
     blocks = []
-    for a in range(0, hi - lo, 20_000):
-        b = min(a + 20_000, hi - lo)
+    for a in range(0, hi - lo, 50_000):
+        b = min(a + 50_000, hi - lo)
         blocks.append((a, b, (rp[a:b + 1] - rp[a]).contiguous(), col[rp_host[a]:max(rp_host[b], rp_host[a] + 1)].contiguous()))
 
     def run():
@@ -318,6 +320,38 @@ def make_freedom_step(dev, nu, ni, eu, ei, gen, lazy=False):
     return freedom_step
 
 
+def c5_fwd_bwd(dev, g, n_nodes, nnz, reps=10):
+    """"report fwd+bwd separately" -- the propagation as the models run it (layer mean fused into the
+    epilogue, Horner-form backward on the transposed = same symmetric graph) through autograd, config-5 graph"""
+    from mmrec_amd import hip_ops
+    gen = torch.Generator(device=dev).manual_seed(3)
+    E = (torch.rand(n_nodes, 64, device=dev, generator=gen) - 0.5).requires_grad_()
+    gO = torch.rand(n_nodes, 64, device=dev, generator=gen) - 0.5
+
+    def fwd():
+        with torch.no_grad():
+            hip_ops.lightgcn_mean(g, E, N_LAYERS)
+
+    def both():
+        E.grad = None
+        hip_ops.lightgcn_mean(g, E, N_LAYERS).backward(gO)
+    out = {}
+    for name, fn, passes in (("fwd", fwd, 1), ("fwd_bwd", both, 2)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out["ms_" + name] = dt * 1e3
+        out["edges_per_s_" + name] = passes * N_LAYERS * nnz / dt
+    out["what"] = ("hip_ops.lightgcn_mean over the config-5 graph, %d layers: forward alone (layer mean fused into the "
+                   "SpMM epilogue) and forward + backward through autograd; edges/s counts nnz x layers x passes" % N_LAYERS)
+    return out
+
+
 def extra_baby(dev):
     """Amazon-Baby-shaped numbers (cache resident): 3-layer propagation, full-sort eval, projection."""
     from mmrec_amd import hip_ops, synth
@@ -329,15 +363,20 @@ def extra_baby(dev):
     gen = torch.Generator(device=dev).manual_seed(0)
     E0 = (torch.rand(n, 64, device=dev, generator=gen) - 0.5) * 0.1
 
-    def timeit(fn, reps=50, warm=5):
+    def timeit(fn, reps=50, warm=5, windows=3):
+        """median over `windows` back-to-back windows of `reps` calls each: one stall of the box (allocator trim, clock
+        ramp: a single 200-call window once read 217 us for a 46 us kernel) does not decide a companion number"""
         for _ in range(warm):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        per = []
+        for _ in range(windows):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / reps)
+        return float(np.median(per))
 
     with torch.no_grad():
         dt = timeit(lambda: hip_ops.lightgcn_mean(g, E0, N_LAYERS))
@@ -381,7 +420,7 @@ def extra_baby(dev):
         X = torch.rand(ni, 4096, device=dev, generator=gen)
         W = torch.rand(64, 4096, device=dev, generator=gen) - 0.5
         b = torch.zeros(64, device=dev)
-        dt = timeit(lambda: hip_ops.linear(X, W, b), reps=200, warm=20)   # ~10 ms window: a 1.5 ms one read 48-94 us run to run
+        dt = timeit(lambda: hip_ops.linear(X, W, b), reps=100, warm=20, windows=5)
         out["baby_linear4096_fwd_us"] = dt * 1e6
         out["baby_linear4096_fwd_tflops"] = 2.0 * ni * 4096 * 64 / dt / 1e12
         out["baby_linear4096_fwd_frac_mfma_f32"] = out["baby_linear4096_fwd_tflops"] / MFMA_F32_PEAK_TF
@@ -801,6 +840,10 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                                      "value": line["extra"]["baby_full_eval_users_per_s"], "unit": "users/s"}
             except Exception as ex:  # the headline number must not be lost to an auxiliary failure
                 line["extra"] = {"error": repr(ex)}
+            try:
+                line["extra"]["c5_propagate_fwd_bwd"] = c5_fwd_bwd(dev, g, n_nodes, nnz_total)
+            except Exception as ex:
+                line["extra"]["c5_propagate_fwd_bwd"] = {"error": repr(ex)}
         if multi:
             line["extra"] = dist_extra
         line.setdefault("extra", {})["c5_full_eval"] = c5_eval

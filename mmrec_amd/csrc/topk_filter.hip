@@ -65,6 +65,8 @@ constexpr int F_SLOW_MASK_LDS = 4096;   // mask entries of such a query staged i
 constexpr int F_SLOW_PARTS = 4096;      // (query, split) partial top-k lists of the split slow path (2 MiB)
 constexpr int F_SLOW_SPLIT_NC = 65536;  // from this many candidates on a flagged query is split over 16 workgroups
 constexpr int F_MIN_NC = 4096;    // below: the materialised path is as fast (fixed launch costs)
+constexpr int F_SPARSE_NC = 32768;   // from this many candidates on pass 2 appends its NON-ZERO 64-bit words to a list
+constexpr int F_WCAP = 256;          // ... of this many (word index, word) entries per query (each holds >= 1 survivor)
 constexpr int F_PF = 4;        // 64-candidate stages in flight per workgroup (register ring)
 constexpr int F_MASK_LDS = 512; // mask entries per query staged in LDS by the final kernel (>= F_MAXR * 32)
 
@@ -191,6 +193,8 @@ struct PassArgs {
     unsigned* gkeys;      // pass 1 out: [nq][n_groups] monotone keys of the group maxima
     const float* thr;     // pass 2 in:  [nq]
     unsigned long long* bits;   // pass 2 out: [nq][ranges][2][stages_per_range / 2] pass / fail bits
+    int* wcnt;            // pass 2 out, SPARSE: [nq] appended words (zeroed by the launcher)
+    uint4* wlist;         // pass 2 out, SPARSE: [nq][F_WCAP] (word index in the row above, 0, word lo, word hi)
 };
 
 // The MFMAs of a stage are issued back to back (four independent accumulator chains, alternating): on gfx950 ANY
@@ -204,7 +208,13 @@ struct PassArgs {
 //          v_alignbit); the 64 bits of two stages go to memory as one 8-byte store per lane and fragment.  No lists,
 //          no atomics, no overflow in the hot loop.  Bit 63 - (16 j + r) of word g of row (q, range, h): candidate
 //          32 (2 (S_r0 + 2 g) + j) + (r & 3) + 8 (r >> 2) + 4 h   (j = 0..3: the four tiles of two stages).
-template <bool FILTER>
+//  SPARSE (large candidate sets): a query's row of pass / fail bits is nc / 8 bytes, all but ~65 of its words zero.  At
+//          500K candidates the rows of one 65,536-query block are 4.1 GB of 8-byte stores scattered over 131,072 rows in
+//          flight (pass 2 took 10.2 ms against 3.5 ms for pass 1, the same products) and the final kernel scans them
+//          again.  Instead a lane appends its NON-ZERO words to the query's list (one atomic slot counter per query;
+//          ~1 % of the words).  The append is software-pipelined: the atomic of one flush is consumed at the next, so no
+//          wave waits a memory round trip in the stage loop.  List order is arbitrary; the final kernel sorts anyway.
+template <bool FILTER, bool SPARSE = false>
 __global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
     __shared__ uint4 s_c[2][2][256];   // [buffer][tile of the stage][row * 8 + swizzled chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -232,8 +242,22 @@ __global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[f][s] = __builtin_bit_cast(half8, a.Qs[(size_t)q * 8 + h * 4 + s]);
         thr[f] = (FILTER && q < a.nq) ? float_below(a.thr[q]) : INFINITY;
-        brow[f] = FILTER ? a.bits + (((size_t)q * gridDim.y + blockIdx.y) * 2 + h) * (a.stages_per_range >> 1) : nullptr;
+        brow[f] = (FILTER && !SPARSE) ? a.bits + (((size_t)q * gridDim.y + blockIdx.y) * 2 + h) * (a.stages_per_range >> 1) : nullptr;
     }
+    // SPARSE: the append in flight per fragment (slot < 0: none)
+    int ps[2] = {-1, -1};
+    unsigned pw[2] = {0u, 0u};
+    unsigned long long pb[2] = {0ull, 0ull};
+    const unsigned wbase = (blockIdx.y * 2 + h) * (a.stages_per_range >> 1);
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (ps[f] >= 0 && ps[f] < F_WCAP)
+                a.wlist[(size_t)(q0 + f * 32 + i) * F_WCAP + ps[f]] =
+                    make_uint4(pw[f], 0u, (unsigned)pb[f], (unsigned)(pb[f] >> 32));
+            ps[f] = -1;
+        }
+    };
     // stage fill: thread -> (row rr, chunk cc) of both tiles
     const int rr = tid >> 3, cc = tid & 7;
     const int slot = rr * 8 + (cc ^ ((rr >> 1) & 7));
@@ -320,9 +344,19 @@ __global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
         }
     };
     auto flush = [&](int g) __attribute__((always_inline)) {   // two stages done: one word per fragment
-        if (FILTER) {
+        if (FILTER && !SPARSE) {
             if (q0 + i < a.nq) brow[0][g] = bw[0];
             if (q0 + 32 + i < a.nq) brow[1][g] = bw[1];
+        }
+        if (FILTER && SPARSE) {
+            commit();   // the previous flush's atomics have long returned
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                if (bw[f] != 0ull && q0 + f * 32 + i < a.nq) {
+                    ps[f] = atomicAdd(a.wcnt + q0 + f * 32 + i, 1);
+                    pw[f] = wbase + (unsigned)g;
+                    pb[f] = bw[f];
+                }
         }
     };
     for (int tb = t0; tb < t1; tb += F_PF) {
@@ -334,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
         flush(((tb - t_r0) >> 1) + 1);
     }
     static_assert(F_PF == 4, "the step sequence above is written for a 4-slot ring");
+    if (FILTER && SPARSE) commit();
     }
     if (!FILTER) {
 #pragma unroll
@@ -522,10 +557,12 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     __syncthreads();   // `merged` / the lists are reused by the workgroup's next query
 }
 
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void filter_final_kernel(
     const float* __restrict__ Q, const float* __restrict__ C, int nq, int nc, int k,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
-    const unsigned long long* __restrict__ bits, int n_ranges, int tiles_per_range, const int* __restrict__ flag,
+    const unsigned long long* __restrict__ bits, const int* __restrict__ wcnt, const uint4* __restrict__ wlist,
+    int n_ranges, int tiles_per_range, const int* __restrict__ flag,
     int* __restrict__ flist, int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
     __shared__ unsigned long long s_l[4][F_CAPQ];   // (score, id) of the unmasked survivors
     __shared__ int s_ids[4][F_CAPQ];
@@ -535,29 +572,41 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     if (q >= nq) return;   // waves are independent below (wave-level fences only)
     // everything the wave needs first is requested at once: the loads do not depend on each other, and a wave's life
     // is a chain of L2 round trips (flag -> mask range -> mask list -> bit words -> query row -> candidate rows)
-    const int gpr = tiles_per_range >> 2, n_words = n_ranges * 2 * gpr;
-    const unsigned long long* row = bits + (size_t)q * n_words;
-    auto word = [&](int wi) -> unsigned long long {
-        const int rg = wi / gpr, g = wi - rg * gpr;               // rg = 2 * range + h
+    const int gpr = tiles_per_range >> 2;
+    // SPARSE: the query's appended (word index, word) entries instead of its row of words
+    const int n_app = SPARSE ? wcnt[q] : 0;
+    const int n_words = SPARSE ? min(n_app, F_WCAP) : n_ranges * 2 * gpr;
+    const unsigned long long* row = SPARSE ? nullptr : bits + (size_t)q * n_words;
+    const uint4* ents = SPARSE ? wlist + (size_t)q * F_WCAP : nullptr;
+    int wi_next = lane;       // index of the word `x_next` (SPARSE: read from the entry)
+    auto word = [&](int e, int& wi) -> unsigned long long {
+        if (SPARSE) {
+            if (e >= n_words) { wi = 0; return 0ull; }
+            const uint4 t = ents[e];
+            wi = (int)t.x;
+            return (unsigned long long)t.z | ((unsigned long long)t.w << 32);
+        }
+        wi = e;
+        const int rg = e / gpr, g = e - rg * gpr;               // rg = 2 * range + h
         // words of tile groups past the last tile are never written by pass 2
-        const bool live = wi < n_words && (rg >> 1) * tiles_per_range + 4 * g < (nc + 31) / 32;
-        return live ? row[wi] : 0ull;
+        const bool live = e < n_words && (rg >> 1) * tiles_per_range + 4 * g < (nc + 31) / 32;
+        return live ? row[e] : 0ull;
     };
-    unsigned long long x_next = word(lane);
+    unsigned long long x_next = word(lane, wi_next);
     const float4 qv = reinterpret_cast<const float4*>(Q)[(size_t)q * 16 + (lane & 15)];
     const int fl = flag[q];
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
-    bool bad = fl != 0 || m > F_MASK_LDS;
+    bool bad = fl != 0 || m > F_MASK_LDS || n_app > F_WCAP;
     if (!bad) {
         // A: decode the pass / fail bits of pass 2 into candidate ids; stage the query's sorted mask list
         for (int e = lane; e < m; e += 64) s_mask[wave][e] = mask_col[m_lo + e];
         const unsigned long long lt = (1ull << lane) - 1ull;
         int n = 0;
         for (int w0 = 0; w0 < n_words; w0 += 64) {
-            const int wi = w0 + lane;
+            const int wi = wi_next;
             const int rg = wi / gpr, g = wi - rg * gpr;
             unsigned long long x = x_next;
-            if (w0 + 64 < n_words) x_next = word(wi + 64);         // the next word travels while this one is decoded
+            if (w0 + 64 < n_words) x_next = word(w0 + lane + 64, wi_next);   // the next word travels while this one is decoded
             const int cbase = ((rg >> 1) * tiles_per_range + 4 * g) * 32 + 4 * (rg & 1);
             for (;;) {
                 const unsigned long long b = __ballot(x != 0ull);
@@ -673,6 +722,8 @@ __global__ __launch_bounds__(256) void filter_slow_merge_kernel(const int* __res
 
 struct FilterPlan {
     int n_stages, qblocks, nq_pad, R, spr, n_groups;   // spr: 64-candidate stages per range
+    bool sparse;                                       // pass 2 -> word lists instead of rows of words
+    size_t bits_bytes;                                 // the region pass 2 writes (rows, or counters + lists)
 };
 inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 inline FilterPlan filter_plan(int nq, int nc) {
@@ -695,6 +746,9 @@ inline FilterPlan filter_plan(int nq, int nc) {
         if ((long)reff * spr * 100 <= best * 106) { p.spr = spr; p.R = reff; }
     }
     p.n_groups = 32 * p.R;
+    p.sparse = nc >= F_SPARSE_NC;
+    p.bits_bytes = p.sparse ? ((((size_t)nq * 4 + 255) & ~(size_t)255) + (size_t)nq * F_WCAP * 16)
+                            : (size_t)nq * p.R * p.spr * 8;
     return p;
 }
 inline size_t al256f(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -708,7 +762,7 @@ bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
 size_t topk64_filter_workspace_bytes(int nq, int nc, int k) {
     const FilterPlan p = filter_plan(nq, nc);
     return al256f((size_t)p.nq_pad * 128) + al256f((size_t)p.n_stages * 64 * 128) + al256f((size_t)p.nq_pad * 4) + 512 +
-           al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f((size_t)nq * p.R * p.spr * 8) +
+           al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f(p.bits_bytes) +
            al256f((size_t)F_SLOW_PARTS * 64 * 8);
 }
 
@@ -727,8 +781,10 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     float* thr = reinterpret_cast<float*>(ws);         ws += al256f((size_t)nq * 4);
     int* flag = reinterpret_cast<int*>(ws);            ws += al256f((size_t)nq * 4);
     int* flist = reinterpret_cast<int*>(ws);           ws += al256f((size_t)nq * 4);
-    unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws);   // [nq][R][2][spr / 2]
-    ws += al256f((size_t)nq * p.R * p.spr * 8);
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws);   // [nq][R][2][spr / 2], or:
+    int* wcnt = reinterpret_cast<int*>(ws);                                 // sparse: [nq] counters, then
+    uint4* wlist = reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4));   //         [nq][F_WCAP] entries
+    ws += al256f(p.bits_bytes);
     unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][64]
     hipError_t e = hipMemsetAsync(stats, 0, 512, s);
     if (e != hipSuccess) return (int)e;
@@ -737,15 +793,26 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
                        Qs, qnorm, (unsigned*)nullptr);
     hipLaunchKernelGGL((filter_convert_kernel<true>), dim3(p.n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc,
                        p.n_stages * 64, stats, Cs, (float*)nullptr, cmax);
-    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, gkeys, thr, bits};
+    if (p.sparse) {
+        e = hipMemsetAsync(wcnt, 0, (size_t)nq * 4, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, gkeys, thr, bits, wcnt, wlist};
     const dim3 grid(p.qblocks, p.R);
     hipLaunchKernelGGL((filter_pass_kernel<false>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
                        mask_rowptr, qnorm, cmax, stats, thr, flag);
-    hipLaunchKernelGGL((filter_pass_kernel<true>), grid, dim3(256), 0, s, a);
+    if (p.sparse)
+        hipLaunchKernelGGL((filter_pass_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((filter_pass_kernel<true, false>), grid, dim3(256), 0, s, a);
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
-    hipLaunchKernelGGL(filter_final_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                       mask_col, bits, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+    if (p.sparse)
+        hipLaunchKernelGGL((filter_final_kernel<true>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+    else
+        hipLaunchKernelGGL((filter_final_kernel<false>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
     const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
     hipLaunchKernelGGL(filter_slow_kernel, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
                        n_flagged, out_idx, out_val, want, parts);

@@ -37,6 +37,27 @@ def rel_fro(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
+def single_rank_rccl_group(dev):
+    """one-rank RCCL process group on a free local port; a port the kernel hands out can still be taken by the time the
+    store binds it (seen once: EADDRINUSE right after the previous test's group was torn down) -> another port"""
+    import os
+    import socket
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for attempt in range(5):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            return
+        except dist.DistNetworkError:
+            if attempt == 4:
+                raise
+
+
 def golden_graph(ops, g, dev, key="norm_adj", **kw):
     n = int(g["n_users"]) + int(g["n_items"])
     return ops.CsrGraph.from_coo_host(g[key + "_idx"], g[key + "_val"], n, n, dev, symmetric=True, **kw)
@@ -634,6 +655,33 @@ def test_topk_slow_queue_split_over_workgroups(ops, dev):
     _topk_check(ops, dev, Qr, Cr, 50, np.stack([key // nc, key % nc]))
 
 
+@pytest.mark.parametrize("nq,nc", [(300, 32768), (517, 40_037), (64, 131_072 + 5)])
+def test_topk_filter_word_lists(ops, dev, nq, nc):
+    """>= 32,768 candidates: pass 2 appends its non-zero 64-bit pass / fail words to per-query lists (atomic slot
+    counters) instead of writing rows of nc / 8 bytes per query, and the final kernel decodes the lists (arbitrary order:
+    the outputs stay deterministic through the final sort).  Exact boundary size, ragged last stage / tile, query
+    counts that are not multiples of 256, realistic masks, one query whose candidates tie massively (> 256 non-zero
+    words: list overflow -> slow queue), one heavy user; checked against the oracle; two calls give identical results."""
+    rng = np.random.default_rng(nq + nc)
+    k = 50
+    Q = rng.standard_normal((nq, 64)).astype(np.float32) * 0.2
+    C = (rng.standard_normal((nc, 64)) * 0.2 + 0.3).astype(np.float32)
+    C[1000:1000 + 20_000:40] = 1.0                     # 500 identical candidates ...
+    Q[7] = 1.0                                         # ... that are this query's best: > 256 words pass -> overflow
+    rows = np.concatenate([rng.integers(0, nq, 20 * nq), np.repeat(11, 3000)])
+    cols = np.concatenate([rng.integers(0, nc, 20 * nq), rng.choice(nc, 3000, replace=False)])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    idx = _topk_check(ops, dev, Q, C, k, mask)
+    masked7 = set(mask[1][mask[0] == 7].tolist())
+    assert idx[7].tolist() == [c for c in range(1000, 21_000, 40) if c not in masked7][:k]      # ties: lowest ids first
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    a = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
+    b = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert np.array_equal(a[0].cpu().numpy(), idx)
+
+
 def test_topk_knn_shape(ops, dev, golden):
     """P6: kNN(k=10) over row-normalised features == freedom.py:79-82 on the golden features."""
     for key, k in (("image_feat", 10), ("text_feat", 10)):
@@ -748,12 +796,7 @@ def test_sharded_propagator_rccl_single_rank(ops, dev):
     import torch.distributed as dist
     from mmrec_amd import synth
     from mmrec_amd.dist import BipartiteSharding, ShardedPropagator
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    single_rank_rccl_group(dev)
     try:
         nu, ni = 3000, 1200
         eu, ei = synth.powerlaw_edges(nu, ni, 40000, seed=2)
@@ -801,12 +844,7 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev):
     from mmrec_amd.common.trainer import Trainer
     from mmrec_amd.utils.utils import get_model
     from tests._env import setup
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    single_rank_rccl_group(dev)
     try:
         res = {}
         for sharded in (False, True):
@@ -990,12 +1028,7 @@ def test_item_replicated_propagator_rccl_single_rank(ops, dev):
     import torch.distributed as dist
     from mmrec_amd import synth
     from mmrec_amd.dist import ItemReplicatedPropagator
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    single_rank_rccl_group(dev)
     try:
         nu, ni = 3000, 1200
         eu, ei = synth.powerlaw_edges(nu, ni, 40000, seed=2)
@@ -1030,12 +1063,7 @@ def test_sharded_training_step_rccl_single_rank(ops, dev):
     import torch.distributed as dist
     from mmrec_amd.dist import ItemReplicatedPropagator, ShardedLightGCNStep
     from mmrec_amd import synth
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    single_rank_rccl_group(dev)
     created = True
     try:
         nu, ni = 900, 400
@@ -1076,12 +1104,7 @@ def test_sharded_projection_and_topk_rccl_single_rank(ops, dev):
     import socket
     import torch.distributed as dist
     from mmrec_amd.dist import hip_local_linear, sharded_projection, sharded_score_topk
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    single_rank_rccl_group(dev)
     try:
         g = torch.Generator().manual_seed(5)
         X = torch.randn(700, 384, generator=g).to(dev)
