@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA
+MFMA_F16_PEAK_TF = 2500.0  # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 N_LAYERS = 3
 
 
@@ -764,7 +765,11 @@ def main():
             tt = torch.tensor([t_eval], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_eval = float(tt.item())
+        flop = 2.0 * sh.n_users * sh.n_items * 64
         c5_eval = {"users_per_s": sh.n_users / t_eval, "seconds": t_eval,
+                   "useful_tflops": flop / t_eval / 1e12,            # one exact score per (user, item) pair
+                   "frac_mfma_f16_two_passes": 2 * flop / t_eval / 1e12 / MFMA_F16_PEAK_TF,   # what the filter executes
+
                    "what": "score + mask + top-50 of all %d users x %d items (the propagated embeddings of the timed step), "
                            "users sharded x%d, item table replicated, no exchange" % (sh.n_users, sh.n_items, world)}
         del Ue, Ie
