@@ -331,7 +331,7 @@ class _LayerGCNSum(torch.autograd.Function):
         if E0.shape[1] != EMB_DIM or E0.shape[0] != g.n_rows or g.n_cols != g.n_rows:
             raise _lib.MMRecHipError("layergcn_sum needs E0 [n, %d] over a square graph of n rows" % EMB_DIM)
         acc = torch.zeros_like(E0) if L == 0 else torch.empty_like(E0)
-        need_y = ctx.needs_input_grad[0]          # the unscaled products are only read by the backward
+        need_y = any(ctx.needs_input_grad)        # the unscaled products are only read by the backward
         ys, ws = [], []
         cur = E0
         for layer in range(L):                    # SpMM + cosine re-weighting + layer sum: ONE launch per layer
@@ -372,6 +372,38 @@ class _LayerGCNSum(torch.autograd.Function):
 
 def layergcn_sum(g: CsrGraph, E0, n_layers):
     return _LayerGCNSum.apply(E0, g, n_layers)
+
+
+class _LayerGCNSumParts(torch.autograd.Function):
+    """_LayerGCNSum on the row-wise concatenation of several tables, result split back into the same row blocks (see
+    _LightGCNMeanParts: the same launches without autograd's cat / slice bookkeeping around them)."""
+
+    @staticmethod
+    def forward(ctx, g, n_layers, *parts):
+        ctx.sizes = [p.shape[0] for p in parts]
+        if row_blocks_of_one_buffer(parts):
+            E0 = parts[0].detach().as_strided((sum(ctx.sizes), parts[0].shape[1]), (parts[0].shape[1], 1))
+        else:
+            E0 = torch.cat([p.detach() for p in parts], dim=0)
+        return tuple(_LayerGCNSum.forward(ctx, E0, g, n_layers).split(ctx.sizes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        like = next(x for x in grads if x is not None)
+        n, d = sum(ctx.sizes), like.shape[1]
+        if row_blocks_of_one_buffer(grads):
+            dSum = grads[0].as_strided((n, d), (d, 1))
+        else:
+            dSum = torch.empty((n, d), dtype=like.dtype, device=like.device)
+            for dst, src in zip(dSum.split(ctx.sizes), grads):
+                dst.zero_() if src is None else dst.copy_(src)
+        t = _LayerGCNSum.backward(ctx, dSum)[0]
+        return (None, None) + tuple(t.split(ctx.sizes))
+
+
+def layergcn_sum_parts(g: CsrGraph, parts, n_layers):
+    """sum_l w_l (A E_{l-1}) over cat(parts) as a tuple of row blocks, one per input table (layergcn.py:125-138)"""
+    return _LayerGCNSumParts.apply(g, n_layers, *parts)
 
 
 # ------------------------------------------------------------------------------------------------

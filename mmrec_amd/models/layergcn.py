@@ -15,11 +15,12 @@ import torch.nn as nn
 from mmrec_amd import hip_ops
 from mmrec_amd.graph import norm_adj_graph
 from mmrec_amd.utils.utils import random_sample_range
-from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender
 
 
-class LayerGCN(FusedEvalMixin, GeneralRecommender):
+class LayerGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
+    adjacent_tables = ('user_embeddings', 'item_embeddings')
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -64,8 +65,7 @@ class LayerGCN(FusedEvalMixin, GeneralRecommender):
         return torch.cat([self.user_embeddings, self.item_embeddings], 0)
 
     def forward(self):
-        out = hip_ops.layergcn_sum(self.forward_adj, self.get_ego_embeddings(), self.n_layers)
-        return out[:self.n_users], out[self.n_users:]
+        return hip_ops.layergcn_sum_parts(self.forward_adj, (self.user_embeddings, self.item_embeddings), self.n_layers)
 
     def eval_embeddings(self):
         self.forward_adj = self.norm_adj_matrix
@@ -75,7 +75,7 @@ class LayerGCN(FusedEvalMixin, GeneralRecommender):
         user, pos, neg = interaction[0], interaction[1], interaction[2]
         self.forward_adj = self.masked_adj
         u_all, i_all = self.forward()
-        mf_loss = hip_ops.bpr_loss(u_all, i_all, user, pos, neg, hip_ops.BPR_LOGSIG, 'sum')
+        mf_loss, = hip_ops.bpr_losses_shared_users(u_all, user, [(i_all, pos, neg)], hip_ops.BPR_LOGSIG, 'sum', joint_grad=True)
         reg_loss = 0.5 * (hip_ops.gather_sqnorm(self.user_embeddings, user) +
                           hip_ops.gather_sqnorm(self.item_embeddings, pos) +
                           hip_ops.gather_sqnorm(self.item_embeddings, neg))

@@ -144,6 +144,11 @@ def layergcn_sum(g, E0, n_layers):
     return torch.stack(outs, 0).sum(0)
 
 
+def layergcn_sum_parts(g, parts, n_layers):
+    sizes = [p.shape[0] for p in parts]
+    return tuple(layergcn_sum(g, torch.cat(list(parts), dim=0), n_layers).split(sizes))
+
+
 def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):
     _mat(U, "U", width_multiple=EMB_DIM), _mat(I, "I", width=U.shape[1])
     _ids(users, "users"), _ids(pos, "pos"), _ids(neg, "neg")
@@ -238,7 +243,8 @@ def spmm_vals(dyn, X, vals):
     return out.index_add(0, dyn.rows, vals.unsqueeze(1) * X[dyn.cols])
 
 
-_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "lightgcn_mean", "lightgcn_mean_parts", "layergcn_sum", "bpr_loss",
+_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "lightgcn_mean", "lightgcn_mean_parts", "layergcn_sum", "layergcn_sum_parts",
+            "bpr_loss",
             "bpr_losses_shared_users", "infonce",
             "gather_sqnorm", "cosine_mean", "linear", "score_topk", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")

@@ -301,6 +301,20 @@ def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden)
     ops.bpr_loss(out[:nu].contiguous(), out[nu:].contiguous(), b[0], b[1], b[2]).backward()
     close(ue.grad, ue2.grad, atol=1e-7, rtol=1e-5)
     close(ie.grad, ie2.grad, atol=1e-7, rtol=1e-5)
+    # LayerGCN's propagation through the same kind of node (layergcn.py:125-152, BPR summed)
+    ue, ie = both[:nu].detach().clone(), both[nu:].detach().clone()
+    both2 = torch.cat([ue, ie], 0)
+    ue, ie = both2[:nu].detach().requires_grad_(), both2[nu:].detach().requires_grad_()
+    u, i = ops.layergcn_sum_parts(graph, (ue, ie), 3)
+    l1, = ops.bpr_losses_shared_users(u, b[0], [(i, b[1], b[2])], ops.BPR_LOGSIG, "sum", joint_grad=True)
+    l1.backward()
+    ue2, ie2 = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
+    out = ops.layergcn_sum(graph, torch.cat([ue2, ie2], 0), 3)
+    l2 = ops.bpr_loss(out[:nu].contiguous(), out[nu:].contiguous(), b[0], b[1], b[2], ops.BPR_LOGSIG, "sum")
+    l2.backward()
+    assert torch.equal(l1, l2) and torch.equal(u, out[:nu]) and torch.equal(i, out[nu:])
+    close(ue.grad, ue2.grad, atol=1e-6, rtol=1e-5)
+    close(ie.grad, ie2.grad, atol=1e-6, rtol=1e-5)
     # an output nobody uses: its gradient slot arrives as None
     ue, ie = D(g["lgn_user_emb"], dev, True), D(g["lgn_item_emb"], dev, True)
     u, i = ops.lightgcn_mean_parts(graph, (ue, ie), 2)
