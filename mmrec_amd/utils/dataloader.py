@@ -11,11 +11,48 @@ single-pass iterators like the reference's (pointer reset on StopIteration).
 import math
 import ctypes
 import random
+import sys
 from logging import getLogger
 
 import numpy as np
 import torch
 from scipy.sparse import coo_matrix
+
+
+_LIVE_MT = []   # [] = not probed yet; [None] = unavailable; [(state pointer, index pointer)]
+
+
+def _live_mt_state():
+    """Pointers to the Mersenne Twister state INSIDE the interpreter's global `random` generator, so that the C sampler
+    (include/mmrec_hip.h: mmrec_host_sample_negatives) draws from it in place instead of through a getstate() / setstate()
+    round trip per batch.  CPython's `_random.Random` object is {PyObject_HEAD; int index; uint32_t state[624]}
+    (Modules/_randommodule.c); the layout is PROBED, not assumed: the view must show exactly what random.getstate() reports,
+    before and after a draw, or the marshalling path stays in use."""
+    if _LIVE_MT:
+        return _LIVE_MT[0]
+    found = None
+    try:
+        inst = getattr(random, '_inst', None)
+        if type(inst) is random.Random and sys.implementation.name == 'cpython':
+            base = id(inst) + ctypes.sizeof(ctypes.c_ssize_t) + ctypes.sizeof(ctypes.c_void_p)      # PyObject_HEAD
+            index = ctypes.c_int.from_address(base)
+            state = (ctypes.c_uint32 * 624).from_address(base + ctypes.sizeof(ctypes.c_int))
+
+            def agrees():
+                internal = random.getstate()[1]
+                return index.value == internal[-1] and tuple(state) == tuple(internal[:-1])
+            saved = random.getstate()
+            ok = agrees()
+            for _ in range(700):              # across a regeneration of the 624-word block
+                random.getrandbits(32)
+            ok = ok and agrees()
+            random.setstate(saved)
+            if ok and agrees():
+                found = (ctypes.cast(state, ctypes.c_void_p), ctypes.cast(ctypes.pointer(index), ctypes.c_void_p))
+    except Exception:
+        found = None
+    _LIVE_MT.append(found)
+    return found
 
 
 class AbstractDataLoader(object):
@@ -200,19 +237,26 @@ class TrainDataLoader(AbstractDataLoader):
                 self._native_sampler = False
         if self._native_sampler is False or self.all_item_len.bit_length() > 32:
             return self._sample_neg_ids_loop(users)
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         if self._items_arr is None:
             self._items_arr = np.ascontiguousarray(self.all_items, dtype=np.int64)
-        version, internal, gauss = random.getstate()
-        mt = np.array(internal[:-1], dtype=np.uint32)
-        idx = ctypes.c_int32(internal[-1])
+            self._const_ptrs = (ptr(self._hist_rowptr), ptr(self._hist_items), ptr(self._items_arr))
         users = np.ascontiguousarray(users, dtype=np.int64)
         out = np.empty(users.shape[0], dtype=np.int64)
-        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        err = self._native_sampler(ptr(mt), ctypes.byref(idx), ptr(users), users.shape[0], ptr(self._hist_rowptr),
-                                   ptr(self._hist_items), ptr(self._items_arr), self.all_item_len, ptr(out))
+        live = _live_mt_state()
+        if live is not None:       # the C sampler continues the interpreter's own generator in place
+            mt_ptr, idx_ptr = live
+        else:                      # marshal the state through random.getstate() / setstate() (36 us per batch)
+            version, internal, gauss = random.getstate()
+            mt = np.array(internal[:-1], dtype=np.uint32)
+            idx = ctypes.c_int32(internal[-1])
+            mt_ptr, idx_ptr = ptr(mt), ctypes.byref(idx)
+        err = self._native_sampler(mt_ptr, idx_ptr, ptr(users), users.shape[0], *self._const_ptrs, self.all_item_len,
+                                   ptr(out))
         if err != 0:
             raise RuntimeError("mmrec_host_sample_negatives failed: %d" % err)
-        random.setstate((version, tuple(mt.tolist()) + (idx.value,), gauss))
+        if live is None:
+            random.setstate((version, tuple(mt.tolist()) + (idx.value,), gauss))
         return out
 
     def _sample_neg_ids_loop(self, users):

@@ -83,6 +83,38 @@ def test_native_host_sampler_equals_python_loop(tmp_path, golden):
         assert all(int(n) not in hist[int(u)] for u, n in zip(users, a))
 
 
+def test_sampler_draws_from_the_interpreters_generator_in_place(tmp_path, golden):
+    """The C sampler works on the Mersenne Twister state INSIDE `random`'s global generator (probed layout of CPython's
+    _random.Random object, utils/dataloader.py:_live_mt_state) instead of a getstate() / setstate() round trip per batch:
+    same negatives and same generator state as the marshalling path and as the reference-form Python loop; interleaved
+    draws by other code see a generator that is always current."""
+    import random
+    import sys
+    import mmrec_amd.utils.dataloader as DL
+    from tests._env import setup
+    config, train_data, _ = setup(tmp_path, golden, "LightGCN", {"n_layers": 3, "reg_weight": 1e-4})
+    DL._LIVE_MT.clear()
+    live = DL._live_mt_state()
+    if sys.implementation.name == "cpython" and sys.version_info[:2] == (3, 10):
+        assert live is not None                      # the interpreter this image ships: the fast path must be the one in use
+    users = np.random.default_rng(1).integers(0, int(golden["n_users"]), 900)
+    outs = {}
+    for mode in ("live", "marshal", "loop"):
+        DL._LIVE_MT.clear()
+        if mode != "live":
+            DL._LIVE_MT.append(None)
+        random.seed(4242)
+        seq = []
+        for _ in range(3):                           # sampler calls interleaved with ordinary draws
+            fn = train_data._sample_neg_ids_loop if mode == "loop" else train_data._sample_neg_ids
+            seq.append(fn(users).tolist())
+            seq.append(random.random())
+            seq.append(random.sample(range(1000), 5))
+        outs[mode] = (seq, random.getstate())
+    DL._LIVE_MT.clear()
+    assert outs["live"] == outs["marshal"] == outs["loop"]
+
+
 def test_user_cooccurrence_graph_matches_reference_script():
     """mmrec_amd.utils.user_graph (one sparse product) vs the dict the reference's preprocessing script
     (O(U^2) Python loop + torch.topk per user) wrote for the same interactions: same counts in the same order,
