@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 5
+#define MMREC_ABI_VERSION 6
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -333,6 +333,21 @@ int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const int64_t* ids
 int mmrec_adam_rows_step_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, const float* g,
                              int32_t n_ids, int32_t F, int32_t* last_step, int32_t t, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int32_t presummed, mmrec_stream_t stream);
+/* The same three calls for a step replayed as a hipGraph (hip_graph_step): nothing step-dependent comes from the host.
+ * step_dev [1] int64 and hyper_dev [2] fp32 are the device scalars mmrec_adam_prepare maintains (step count; lr / (1 -
+ * b1^t), 1 / sqrt(1 - b2^t)).  Order inside a step: catchup_dev (before prepare: step_dev = steps taken so far) ...
+ * backward ... mmrec_adam_prepare ... hist_set_dev ... rows_step_dev.  hist_set_dev does not write beyond `capacity`
+ * entries: it raises *overflow (sticky, device int32) instead, which the host checks between epochs. */
+int mmrec_adam_hist_set_dev(float* hist, int32_t capacity, const int64_t* step_dev, const float* hyper_dev,
+                            int32_t* overflow, mmrec_stream_t stream);
+int mmrec_adam_rows_catchup_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, int32_t n_ids,
+                                    int32_t n_rows, int32_t F, int32_t* last_step, const float* hist,
+                                    const int64_t* step_dev, float beta1, float beta2, float eps, float weight_decay,
+                                    mmrec_stream_t stream);
+int mmrec_adam_rows_step_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, const float* g,
+                                 int32_t n_ids, int32_t F, int32_t* last_step, const int64_t* step_dev,
+                                 const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
+                                 int32_t presummed, mmrec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -5,14 +5,16 @@ of the time (LayerGCN on Baby: ~0.35 ms of kernels in a 1.7 ms step).  The step 
 epoch -- models rebuild their pruned graph in `pre_epoch_processing`, which changes buffers and launch
 geometry -- with the batch ids in a static buffer, and replayed for every full-size batch.  Capturing
 does not execute anything, so no extra optimizer step is taken; the kernels and their order are the
-eager ones.  Requires the capturable HipAdam (device-side step count / learning rate).
+eager ones.  Requires the capturable HipAdam (device-side step count / learning rate); row-lazy feature tables
+(common/lazy_rows.py) take their step-dependent scalars from the same device counters.
 """
 import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, loss_func=None):
+    def __init__(self, model, optimizer, loss_func=None, steps_per_capture=None):
         self.model, self.opt = model, optimizer
+        self.steps_per_capture = steps_per_capture   # replays one capture may see (an epoch): row-lazy tables reserve for it
         self.loss_func = loss_func or model.calculate_loss
         self.graph = None
         self.static_batch = None
@@ -26,7 +28,10 @@ class GraphedTrainStep:
 
     def _capture(self, batch):
         self.static_batch = batch.clone()
-        self.opt.init_state()
+        try:
+            self.opt.init_state(self.steps_per_capture)
+        except TypeError:                            # an optimizer without row-lazy tables to reserve for
+            self.opt.init_state()
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

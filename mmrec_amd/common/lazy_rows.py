@@ -20,7 +20,6 @@ import torch
 import torch.nn as nn
 
 from mmrec_amd import _lib
-from mmrec_amd.utils.utils import graph_step_mode
 
 INT_MAX = 2 ** 31 - 1
 MAX_IDS = 16000           # MMREC_ADAM_ROWS_MAX_IDS (include/mmrec_hip.h)
@@ -80,6 +79,8 @@ class LazyRowEmbedding(nn.Embedding):
         self._opt = None                        # (exp_avg, exp_avg_sq, hyper) once the optimizer has seen us
         self._t = 0                             # optimizer steps taken on this table
         self._last_step = self._owner = self._hist = None
+        self._dev = None                        # (step_dev int64[1], hyper_dev fp32[2]) of a capturable HipAdam: graph replay
+        self._overflow = None                   # device flag: a step beyond the capacity of `_hist` (checked per epoch)
         self._prefetched = None                 # (ids, event) of a catch-up running on the side stream
         self.allow_missing = False              # True: rows(ids) accepts -1 = "no row" (item-sharded tables: slots of other ranks)
 
@@ -94,12 +95,36 @@ class LazyRowEmbedding(nn.Embedding):
             self._hist = torch.zeros(1024, 2, dtype=torch.float32, device=w.device)
         return w
 
-    def _bind(self, exp_avg, exp_avg_sq, hyper):
+    def _bind(self, exp_avg, exp_avg_sq, hyper, dev=None):
         self._opt = (exp_avg, exp_avg_sq, hyper)
+        self._dev = dev
+
+    # ---- hipGraph replay (capturable HipAdam): nothing step-dependent comes from the host
+    def steps_on_device(self):
+        """optimizer steps taken so far according to the device counter (one host sync)"""
+        return int(self._dev[0].item()) if self._dev is not None else self._t
+
+    def reserve(self, n_more):
+        """Make room in the per-step scalar table for `n_more` further optimizer steps.  Called OUTSIDE a capture (once per
+        capture, i.e. per epoch): a captured step cannot grow the table, it raises the overflow flag instead."""
+        w = self._state()
+        if self._dev is not None:
+            self._t = max(self._t, self.steps_on_device())
+            self.check_overflow()
+        need = self._t + int(n_more) + 2
+        if need > self._hist.shape[0]:
+            grown = torch.zeros(max(need, 2 * self._hist.shape[0]), 2, dtype=torch.float32, device=w.device)
+            grown[:self._hist.shape[0]] = self._hist
+            self._hist = grown
+
+    def check_overflow(self):
+        if self._overflow is not None and int(self._overflow.item()):
+            raise _lib.MMRecHipError("row-lazy Adam: more replayed optimizer steps than reserve() made room for; the "
+                                     "feature table is not up to date (GraphedTrainStep reserves per epoch)")
 
     def _catch_up(self, ids):
         """rows of `ids` (None: all) -> state after the `self._t` optimizer steps taken so far"""
-        if self._opt is None or self._t == 0:
+        if self._opt is None or (self._t == 0 and self._dev is None):
             return
         w = self._state()
         m, v, (b1, b2, eps, wd) = self._opt
@@ -107,6 +132,12 @@ class LazyRowEmbedding(nn.Embedding):
         n = 0 if ids is None else ids.numel()
         if ids is not None:
             _lib.check(lib.mmrec_adam_rows_owner(_p(ids), n, _p(self._owner), _stream()), "adam_rows_owner")
+        if self._dev is not None:
+            _lib.check(lib.mmrec_adam_rows_catchup_dev_f32(
+                _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
+                w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), _p(self._dev[0]), b1, b2, eps, wd,
+                _stream()), "adam_rows_catchup_dev")
+            return
         _lib.check(lib.mmrec_adam_rows_catchup_f32(
             _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
             w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._t, b1, b2, eps, wd, _stream()),
@@ -117,8 +148,10 @@ class LazyRowEmbedding(nn.Embedding):
         (~100 us per table and step at Sports size) and needs nothing the rest of the step produces, while the graph
         propagation the models run first is a chain of short latency-bound launches that leaves HBM idle: a model that
         knows its row ids before it propagates calls this first, and the matching `rows(ids)` only waits for the event."""
-        if self._opt is None or self._t == 0 or not ids.is_cuda:
+        if self._opt is None or (self._t == 0 and self._dev is None) or not ids.is_cuda:
             return
+        if torch.cuda.is_current_stream_capturing():
+            return                               # a captured step keeps to one stream: rows() catches up in line
         ids = ids.contiguous()
         side = _side_stream(ids.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -146,12 +179,19 @@ class LazyRowEmbedding(nn.Embedding):
     @torch.no_grad()
     def flush(self):
         """apply every postponed update: afterwards `weight` (and the moments) equal dense Adam's"""
+        if self._dev is not None:
+            self.check_overflow()
         self._catch_up(None)
 
     # ---- called by HipAdam.step()
     @torch.no_grad()
     def _apply_step(self, lr, b1, b2, eps, wd):
         if not self._pending:
+            if self._dev is not None and self.steps_on_device() > 0:
+                # the device step counter is the optimizer's: a step that skips this table would leave a hole in its
+                # per-step scalars (dense Adam skips a parameter without gradient; a later catch-up could not)
+                raise _lib.MMRecHipError("a row-lazy table under a capturable (hipGraph) optimizer must be used in every "
+                                         "training step; set lazy_feature_adam: False or hip_graph_step: False")
             return False
         w = self._state()
         m, v, _ = self._opt
@@ -160,12 +200,20 @@ class LazyRowEmbedding(nn.Embedding):
         dY = torch.cat([g for _, g in self._pending]) if len(self._pending) > 1 else self._pending[0][1]
         self._pending = []
         n = ids.numel()
-        self._t += 1
-        if self._t >= self._hist.shape[0]:
-            grown = torch.zeros(2 * self._hist.shape[0], 2, dtype=torch.float32, device=w.device)
-            grown[:self._hist.shape[0]] = self._hist
-            self._hist = grown
-        _lib.check(lib.mmrec_adam_hist_set(_p(self._hist), self._t, float(lr), b1, b2, _stream()), "adam_hist_set")
+        self._t += 1                              # (under graph replay: a mirror that advances per capture; see reserve)
+        if self._dev is not None:
+            if self._overflow is None:
+                self._overflow = torch.zeros(1, dtype=torch.int32, device=w.device)
+            if not torch.cuda.is_current_stream_capturing() and self._t + 2 > self._hist.shape[0]:
+                self.reserve(1024)
+            _lib.check(lib.mmrec_adam_hist_set_dev(_p(self._hist), self._hist.shape[0], _p(self._dev[0]), _p(self._dev[1]),
+                                                   _p(self._overflow), _stream()), "adam_hist_set_dev")
+        else:
+            if self._t >= self._hist.shape[0]:
+                grown = torch.zeros(2 * self._hist.shape[0], 2, dtype=torch.float32, device=w.device)
+                grown[:self._hist.shape[0]] = self._hist
+                self._hist = grown
+            _lib.check(lib.mmrec_adam_hist_set(_p(self._hist), self._t, float(lr), b1, b2, _stream()), "adam_hist_set")
         _lib.check(lib.mmrec_adam_rows_owner(_p(ids), n, _p(self._owner), _stream()), "adam_rows_owner")
         # rows used through several calls of this step were caught up by the first one.  The workgroup of a row's first
         # occurrence sums the row's occurrences itself, in position order (deterministic; no zero-fill + index_add_ pass
@@ -177,6 +225,11 @@ class LazyRowEmbedding(nn.Embedding):
             g = torch.zeros_like(dY).index_add_(0, slots[present], dY[present])
         else:
             g = dY
+        if self._dev is not None:
+            _lib.check(lib.mmrec_adam_rows_step_dev_f32(_p(w), _p(m), _p(v), _p(ids), _p(self._owner), _p(g), n, w.shape[1],
+                                                        _p(self._last_step), _p(self._dev[0]), _p(self._dev[1]), b1, b2,
+                                                        eps, wd, int(presummed), _stream()), "adam_rows_step_dev")
+            return True
         _lib.check(lib.mmrec_adam_rows_step_f32(_p(w), _p(m), _p(v), _p(ids), _p(self._owner), _p(g), n, w.shape[1],
                                                 _p(self._last_step), self._t, float(lr), b1, b2, eps, wd, int(presummed),
                                                 _stream()),
@@ -189,13 +242,13 @@ AUTO_MIN_ELEMENTS = 64 << 20   # automatic mode: tables from 64 Mi elements (256
 
 def lazy_adam_enabled(config, n_elements=0):
     """`lazy_feature_adam`: True / False, or absent = automatic.  Possible whenever the fused HIP Adam runs the step
-    eagerly (learner adam, hip_fused_adam on, GPU, no hipGraph replay); the update is bit-identical either way.
+    (learner adam, hip_fused_adam on, GPU; eager or replayed as a hipGraph); the update is bit-identical either way.
     Automatic mode turns it on for large tables only: the ~20 extra small launches of a step cost ~0.25 ms, more than
     dense Adam over the Amazon-Baby tables (31.6 M elements: 0.17 ms; measured 0.76 -> 1.02 ms per step), less than
     it from Sports (75 M: 1.90 -> 1.73 ms) and Clothing (3.36 -> 2.50 ms) up, 4.6 x at 500K items."""
     want = config['lazy_feature_adam']
     ok = (str(config['learner']).lower() == 'adam' and config['hip_fused_adam'] in (None, True) and
-          graph_step_mode(config) != 'on' and not config['clip_grad_norm'] and    # clipping needs the dense .grad
+          not config['clip_grad_norm'] and    # clipping needs the dense .grad
           getattr(config['device'], 'type', str(config['device'])) == 'cuda')
     return (ok and n_elements >= AUTO_MIN_ELEMENTS) if want is None else (bool(want) and ok)
 

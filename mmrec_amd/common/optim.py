@@ -33,12 +33,17 @@ class HipAdam(torch.optim.Optimizer):
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
 
-    def init_state(self):
-        """Allocate all moments (and device scalars) up front -- needed before a graph capture."""
+    def init_state(self, steps_ahead=None):
+        """Allocate all moments (and device scalars) up front -- needed before a graph capture.  steps_ahead: optimizer
+        steps the capture about to be made may be replayed for (row-lazy tables keep one pair of scalars per step in a
+        device table that a captured step cannot grow)."""
         for group in self.param_groups:
             for p in group['params']:
                 if p.requires_grad:
                     self._moments(p)
+                    table = getattr(p, '_lazy_table', None)
+                    if table is not None and self.capturable and table._opt is not None:
+                        table.reserve(steps_ahead if steps_ahead is not None else 1 << 16)
             if self.capturable:
                 self._group_dev(group)
 
@@ -66,7 +71,7 @@ class HipAdam(torch.optim.Optimizer):
                 if id(group) in self._dev:
                     n = int(self._dev[id(group)][0].item())
                     for p in group['params']:
-                        if p in self.state and self.state[p] and getattr(p, '_lazy_table', None) is None:
+                        if p in self.state and self.state[p]:
                             self.state[p]['step'] = n
         return super().state_dict()
 
@@ -91,11 +96,10 @@ class HipAdam(torch.optim.Optimizer):
             for p in group['params']:
                 table = getattr(p, '_lazy_table', None)
                 if table is not None:   # row-lazy exact Adam (common/lazy_rows.py): only the touched rows are visited
-                    if self.capturable:
-                        raise _lib.MMRecHipError("row-lazy tables cannot be captured in a hipGraph step")
                     st = self._moments(p)
                     table._bind(st['exp_avg'], st['exp_avg_sq'],
-                                (float(b1), float(b2), float(group['eps']), float(group['weight_decay'])))
+                                (float(b1), float(b2), float(group['eps']), float(group['weight_decay'])),
+                                dev=(step_dev, hyper) if self.capturable else None)
                     if table._apply_step(group['lr'], float(b1), float(b2), float(group['eps']),
                                          float(group['weight_decay'])):
                         st['step'] += 1

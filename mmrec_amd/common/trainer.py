@@ -107,6 +107,10 @@ class Trainer(AbstractTrainer):
         graphed = self._graphed_step(loss_func)
         if graphed is not None:
             graphed.invalidate()        # pre_epoch_processing may have rebuilt the model's graphs
+            try:                        # replays one capture will see: row-lazy tables reserve their per-step scalars for it
+                graphed.steps_per_capture = len(train_data) + 2
+            except TypeError:
+                graphed.steps_per_capture = None
         for batch_idx, interaction in enumerate(train_data):
             if graphed is not None:
                 per_batch.append(graphed(interaction).detach().clone())

@@ -41,8 +41,6 @@ class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         self.lazy_feature_adam = lazy_adam_enabled(config, n_feat) and self.lazy_projection
         self.lazy_prefetch = config['lazy_prefetch'] is not False    # new key: catch-up on a side stream (default on)
         table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
-        if self.lazy_feature_adam:
-            self.graph_capturable = False
         self.norm_adj = norm_adj_graph(dataset.inter_matrix(form='coo').astype(np.float32),
                                        self.n_users, self.n_items, self.device)
         self.user_embedding = nn.Embedding(self.n_users, self.embedding_dim)

@@ -97,8 +97,6 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_id_embedding.weight)
         table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
-        if self.lazy_feature_adam:
-            self.graph_capturable = False     # per-step row lists: not a fixed hipGraph
         if self.v_feat is not None:
             self.image_embedding = table.from_pretrained(self.v_feat, freeze=False)
             self.image_trs = nn.Linear(self.v_feat.shape[1], self.feat_embed_dim)

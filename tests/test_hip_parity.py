@@ -963,6 +963,61 @@ def test_lazy_row_adam_equals_dense(dev):
         assert torch.equal(ol, od) and opt_l.state[lazy.weight]["step"] == 12
 
 
+def test_lazy_row_adam_under_graph_replay_equals_dense(dev):
+    """Round-1 review item 8: the row-lazy Adam inside a REPLAYED hipGraph step.  The step-dependent scalars come from the
+    capturable HipAdam's device counters (mmrec_adam_*_dev entry points), the per-step table is reserved per capture.
+    Three 'epochs' of a GraphedTrainStep (eager warm-up step, re-capture per epoch, a short last batch run eagerly, a
+    learning-rate change between epochs, many more replays than the table's initial 1024 entries) on a model with a lazy
+    table == the same run with a dense table under the same capturable optimizer, bit for bit (weights and both moments
+    after flush()); the device step counter equals the number of steps taken."""
+    from mmrec_amd.common.graph_step import GraphedTrainStep
+    from mmrec_amd.common.lazy_rows import LazyRowEmbedding
+    from mmrec_amd.common.optim import HipAdam
+    n, F, B = 400, 64, 96
+    g = torch.Generator().manual_seed(9)
+    w0, lin0 = torch.randn(n, F, generator=g), torch.randn(F, 8, generator=g) * 0.1
+    # dyadic gradient coefficients: duplicate rows are summed in different orders by the two paths (see the eager test)
+    coefs = (torch.randint(-8, 9, (n, F), generator=g).float() / 8).to(dev)
+    epochs = [[torch.randint(0, 50 if (e + b) % 3 else n, (1, B if b < 420 else 31), generator=g) for b in range(421)]
+              for e in range(3)]                                      # 1263 steps > 1024; last batch of an epoch is short
+
+    class Net(torch.nn.Module):
+        def __init__(self, lazy):
+            super().__init__()
+            cls = LazyRowEmbedding if lazy else torch.nn.Embedding
+            self.table = cls.from_pretrained(w0.clone(), freeze=False)
+            self.lin = torch.nn.Parameter(lin0.clone())
+            self.lazy = lazy
+
+        def calculate_loss(self, batch):
+            ids = batch[0]
+            rows = self.table.rows(ids) if self.lazy else self.table.weight[ids]
+            return (rows * coefs[ids]).sum() + (self.lin ** 2).sum()
+
+    def run(lazy):
+        net = Net(lazy).to(dev)
+        opt = HipAdam(net.parameters(), lr=1e-2, capturable=True)
+        step = GraphedTrainStep(net, opt)
+        for e, batches in enumerate(epochs):
+            for group in opt.param_groups:
+                group["lr"] = 1e-2 * 0.7 ** e
+            step.invalidate()
+            step.steps_per_capture = len(batches) + 2
+            for b in batches:
+                step(b.to(dev))
+        assert not step.failed and step.graph is not None             # the step really was captured and replayed
+        if lazy:
+            assert net.table.steps_on_device() == sum(len(b) for b in epochs)
+            net.table.flush()
+        torch.cuda.synchronize()
+        st = opt.state[net.table.weight]
+        return net.table.weight.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), net.lin.detach().clone()
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert not torch.equal(a[0].cpu(), w0)
+
+
 def test_lazy_row_adam_skips_missing_rows(dev):
     """item-sharded feature tables (ShardedFREEDOM): a batch slot whose item another rank owns is id -1 = "no row" -- a
     zero row forward, no gradient, no catch-up / step work; the present rows evolve exactly as under dense Adam."""

@@ -145,7 +145,8 @@ def test_fp16_filter_error_bound_holds():
 
 def test_config_helpers_for_added_keys():
     """eval_batch_size(): the reference's 4096 unless the fused evaluation runs on the GPU; lazy_adam_enabled(): off on
-    the CPU / with hipGraph replay / without the fused Adam, automatic only for large tables, forced by True / False."""
+    the CPU / without the fused Adam / with gradient clipping, automatic only for large tables, forced by True / False;
+    hipGraph replay of the step is no obstacle any more (the tables read the optimizer's device counters)."""
     from mmrec_amd.common.lazy_rows import AUTO_MIN_ELEMENTS, lazy_adam_enabled
     from mmrec_amd.utils.utils import eval_batch_size
 
@@ -163,7 +164,7 @@ def test_config_helpers_for_added_keys():
     assert lazy_adam_enabled(Cfg(base, device=gpu, lazy_feature_adam=True), small)
     assert not lazy_adam_enabled(Cfg(base, device=gpu, lazy_feature_adam=False), big)
     assert not lazy_adam_enabled(Cfg(base, device=cpu, lazy_feature_adam=True), big)
-    assert not lazy_adam_enabled(Cfg(base, device=gpu, hip_graph_step=True), big)
+    assert lazy_adam_enabled(Cfg(base, device=gpu, hip_graph_step=True), big)
     assert not lazy_adam_enabled(Cfg(base, device=gpu, learner="sgd"), big)
     assert not lazy_adam_enabled(Cfg(base, device=gpu, clip_grad_norm={"max_norm": 1.0}), big)
     assert not lazy_adam_enabled(Cfg(base, device=gpu, hip_fused_adam=False, lazy_feature_adam=True), big)
