@@ -22,6 +22,9 @@ import torch.nn as nn
 from mmrec_amd import _lib
 
 INT_MAX = 2 ** 31 - 1
+# while a step is being captured into a hipGraph, the side-stream catch-up becomes a parallel branch of the graph
+# (fork: side.wait_stream(capturing stream); join: wait_event in rows()); False = one stream, catch-up in line
+PREFETCH_IN_CAPTURE = True
 MAX_IDS = 16000           # MMREC_ADAM_ROWS_MAX_IDS (include/mmrec_hip.h)
 
 
@@ -150,8 +153,8 @@ class LazyRowEmbedding(nn.Embedding):
         knows its row ids before it propagates calls this first, and the matching `rows(ids)` only waits for the event."""
         if self._opt is None or (self._t == 0 and self._dev is None) or not ids.is_cuda:
             return
-        if torch.cuda.is_current_stream_capturing():
-            return                               # a captured step keeps to one stream: rows() catches up in line
+        if torch.cuda.is_current_stream_capturing() and not PREFETCH_IN_CAPTURE:
+            return                               # the captured step keeps to one stream: rows() catches up in line
         ids = ids.contiguous()
         side = _side_stream(ids.device)
         side.wait_stream(torch.cuda.current_stream())

@@ -49,6 +49,10 @@ def main():
     for sharded in ((False,) if os.environ.get("MMREC_C5_PLAIN_ONLY") else (False, True)):
         cd = dict(gpu_id=0, use_gpu=True, data_path=root + "/", epochs=1, save_recommended_topk=False, dropout=0.8,
                   reg_weight=1e-3, dist_force_collectives=True)
+        if os.environ.get("MMREC_C5_EAGER"):
+            cd["hip_graph_step"] = False
+        if os.environ.get("MMREC_C5_NO_PREFETCH"):
+            cd["lazy_prefetch"] = False
         config = Config("FREEDOM", "c5", cd)
         for k, v in cd.items():
             config[k] = v
