@@ -95,12 +95,13 @@ def main():
         losses[sharded] = [float(x) for x in per]
         log("sharded=%s: %d training steps, %.2f ms/step (loss first %.6f last %.6f)" %
             (sharded, steps, dt / steps * 1e3, losses[sharded][0], losses[sharded][-1]))
-        t = time.time()
-        res = trainer.evaluate(valid_data)
-        torch.cuda.synchronize()
-        dt = time.time() - t
-        log("sharded=%s: evaluation of %d users in %.2fs (%.0f users/s incl. metrics), recall@20 %.4f" %
-            (sharded, valid_data.pr_end, dt, valid_data.pr_end / dt, res["recall@20"]))
+        for which in ("first (builds the per-batch mask CSRs, cached on the loader)", "second"):
+            t = time.time()
+            res = trainer.evaluate(valid_data)
+            torch.cuda.synchronize()
+            dt = time.time() - t
+            log("sharded=%s: %s evaluation of %d users in %.2fs (%.0f users/s incl. metrics), recall@20 %.4f" %
+                (sharded, which, valid_data.pr_end, dt, valid_data.pr_end / dt, res["recall@20"]))
         log("sharded=%s: peak device memory %.1f GB" % (sharded, torch.cuda.max_memory_allocated() / 2 ** 30))
         del model, trainer, train_data, valid_data, data
         torch.cuda.empty_cache()
