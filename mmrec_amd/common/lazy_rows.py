@@ -13,6 +13,9 @@ state_dict) whose rows are brought up to date on demand and updated only where t
 The result equals dense Adam bit for bit (tests/test_hip_parity.py::test_lazy_row_adam_equals_dense).  `flush()`
 replays everything that is still postponed (before the table is read as a whole: state_dict, export).
 No host synchronisation anywhere: duplicates are resolved by an `owner` array on the device, not by sort / unique.
+Under a capturable HipAdam (hipGraph replay of the training step, common/graph_step.py) nothing step-dependent comes from
+the host either: the step count and the two bias-correction scalars are read from the optimizer's device counters
+(`mmrec_adam_*_dev`), and the per-step scalar table is reserved per capture (`reserve`).
 """
 import ctypes
 
