@@ -67,7 +67,7 @@ def _worker(rank, world, port, out, n_chunks, balanced):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_chunks,balanced", [(2, 1, False), (2, 2, True), (3, 3, True)])
+@pytest.mark.parametrize("world,n_chunks,balanced", [(2, 1, False), (2, 2, True), (3, 3, True), (8, 2, True)])
 def test_sharded_equals_single(tmp_path, world, n_chunks, balanced):
     """equal-row and nnz-balanced blocks, 1..3 chunks per rank (chunk-major padded space, one all-gather per chunk)"""
     out = str(tmp_path / "outs.pt")
@@ -438,6 +438,7 @@ def _freedom_run(root, golden, world):
 
 def _worker_freedom(rank, world, port, root, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))     # `world` processes share the host's cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import _cpu_ops
     _cpu_ops.install()
@@ -448,7 +449,7 @@ def _worker_freedom(rank, world, port, root, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_freedom_plugin_matches_single_process(tmp_path, golden, cpu_ops, world):
     """BASELINE config 5's model over `n_gpus` processes (row-sharded graphs + all-gather per layer, item-sharded feature
     tables with the batch's projected rows exchanged, replicated id tables): same batches, same injected draws (the
