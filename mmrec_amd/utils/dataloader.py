@@ -312,6 +312,7 @@ class EvalDataLoader(AbstractDataLoader):
         eval_flat, eval_len = self._lists_in_user_order(dataset.df[uid].values, dataset.df[iid].values, eval_u)
         self.eval_items_per_u = np.split(eval_flat, np.cumsum(eval_len)[:-1]) if len(eval_u) else []
         self.eval_len_list = np.asarray(eval_len)
+        self._eval_flat = eval_flat            # the same lists, concatenated: what the device metrics build their CSR from
         self.eval_u = torch.tensor(eval_u).type(torch.LongTensor).to(self.device)
         self._batch_cache = {}
 

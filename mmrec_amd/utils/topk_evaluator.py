@@ -60,7 +60,11 @@ class TopKEvaluator(object):
             self._dump(topk_index.cpu().numpy(), eval_data, idx)
         gt = getattr(eval_data, '_gt_csr', None)
         if gt is None or gt[0].device != topk_index.device:
-            gt = hip_ops.lists_to_csr(eval_data.get_eval_items(), topk_index.device)
+            flat = getattr(eval_data, '_eval_flat', None)
+            if flat is not None:               # our EvalDataLoader: the lists exist concatenated already
+                gt = hip_ops.flat_to_csr(flat, eval_data.get_eval_len_list(), topk_index.device)
+            else:
+                gt = hip_ops.lists_to_csr(eval_data.get_eval_items(), topk_index.device)
             eval_data._gt_csr = gt
         assert gt[0].numel() - 1 == topk_index.shape[0]
         ks = sorted(self.topk)
