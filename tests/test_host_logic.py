@@ -261,3 +261,21 @@ def test_config_objects_equal_the_reference_configs(tmp_path, monkeypatch):
             assert not diff, (name, mg, diff)
             assert str(ra["device"]) == str(rb["device"])
             assert a["no_such_key"] is None and b["no_such_key"] is None
+
+
+def test_ground_truth_csr_from_flat_lists_equals_per_list_sort():
+    """hip_ops.flat_to_csr (one global sort of (row, id) keys; what the device metrics use for 1M evaluation users) ==
+    the per-list construction: row pointers, ids ascending inside every row, empty rows, an empty input."""
+    from mmrec_amd import hip_ops
+    rng = np.random.default_rng(2)
+    lens = rng.integers(0, 7, 5000)
+    lens[[0, 17, 4999]] = 0
+    flat = rng.integers(0, 30000, int(lens.sum()))
+    lists = np.split(flat, np.cumsum(lens)[:-1])
+    rp, ids = hip_ops.flat_to_csr(flat, lens, "cpu")
+    rp2, ids2 = hip_ops.lists_to_csr(lists, "cpu")
+    assert torch.equal(rp, rp2) and torch.equal(ids, ids2) and rp.dtype == torch.int32 and ids.dtype == torch.int32
+    ref = np.concatenate([np.sort(x) for x in lists])
+    assert np.array_equal(ids.numpy(), ref) and np.array_equal(rp.numpy(), np.concatenate([[0], np.cumsum(lens)]))
+    rp, ids = hip_ops.flat_to_csr(np.zeros(0, np.int64), np.zeros(3, np.int64), "cpu")
+    assert rp.tolist() == [0, 0, 0, 0] and ids.numel() == 1
