@@ -533,6 +533,63 @@ def committed_traffic():
         return None
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (the command line the driver
+    contract names: torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) and pass rank 0's ONE JSON line
+    through on stdout.  The reference has no launcher to mirror (src/main.py:16-27 is single-process)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("no torchrun environment: launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """--dry-run: everything of an N-rank run EXCEPT the device work -- process group (gloo), the nnz-balanced row cut
+    of a small graph of the c5 kind, one collective, rank 0's one JSON line.  What tests/test_bench_launcher.py
+    drives on a box without GPUs; no kernel runs and no number is reported."""
+    import torch.distributed as dist
+    from mmrec_amd import synth
+    from mmrec_amd.dist import BipartiteSharding
+    multi = world > 1
+    saved = None
+    if multi:
+        sys.stdout.flush()
+        saved = os.dup(1)                      # gloo / RCCL print banners on stdout: parked on stderr meanwhile
+        os.dup2(2, 1)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    nu, ni = 3000, 1200
+    eu, ei = synth.powerlaw_edges(nu, ni, 30000, seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    sh = BipartiteSharding.from_coo(r, nu, ni, world, n_chunks=args.chunks or 1)
+    per_rank = sh.nnz_per_rank(r)
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = int(per_rank[rank])
+    if multi:
+        dist.all_reduce(seen)
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+    if rank == 0:
+        print(json.dumps({"metric": "GCN-layer edges/sec (3-layer user-item CSR SpMM, d=64, fp32)", "value": None,
+                          "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "ranks_in_process_group": dist.get_world_size() if multi else 1,
+                          "extra": {"nnz_per_rank": [int(x) for x in seen.tolist()]}}), flush=True)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -551,15 +608,22 @@ def main():
                          "'allreduce' = users sharded / items replicated, item partial sums all-reduced per "
                          "layer (2/3 of the volume, fp32-rounding-equal)")
     ap.add_argument("--chunks", type=int, default=None, help="row chunks per rank of the allgather layout (default: auto)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group / sharding-plan self-test: no device work, no numbers (runs without a GPU)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args.pmc_child)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks (torchrun form keeps working: it sets WORLD_SIZE)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -628,11 +692,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    local_t = {}
+
     def timed_steps(fn, n):
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        torch.cuda.synchronize()
+        local_t["own"] = time.perf_counter() - t0     # this rank's own clock, before it waits for the others
         fence()
         t = time.perf_counter() - t0
         if multi:
@@ -652,8 +720,24 @@ def main():
     timed = True
     dt = timed_steps(step, args.steps)
     timed = False
-    state = {"dist_extra": None, "c5_eval": None, "done": False}
+    state = {"dist_extra": None, "c5_eval": None, "done": False, "per_rank": None}
     timed_events = list(ev)
+    if multi:
+        # every rank's own view, gathered NOW (the emitting code may run on a watchdog thread: no collectives there):
+        # own wall time per step, mean SpMM call duration, gather-model GB/s of its calls
+        ms = np.array([s_.elapsed_time(e_) for s_, e_, _, _ in timed_events])
+        ab = np.array([alg_bytes(nz, nr) for _, _, nz, nr in timed_events], dtype=np.float64)
+        mine = torch.tensor([local_t["own"] / args.steps * 1e3, float(ms.mean()), float(ab.sum() / (ms.sum() * 1e-3) / 1e9),
+                             float(len(ms))], device=dev, dtype=torch.float64)
+        allr = torch.empty(world * 4, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 4).cpu().numpy()
+        state["per_rank"] = {"ranks_in_process_group": dist.get_world_size(),
+                             "ms_per_step": [float(x) for x in allr[:, 0]],
+                             "spmm_ms_per_call": [float(x) for x in allr[:, 1]],
+                             "spmm_gather_model_gbs": [float(x) for x in allr[:, 2]],
+                             "spmm_frac_gather_model": [float(x) / HBM_PEAK_GBS for x in allr[:, 2]],
+                             "spmm_calls_timed": [int(x) for x in allr[:, 3]]}
 
     def emit():
         emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total, dt, timed_events, state)
@@ -851,6 +935,8 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                 line["extra"]["c5_propagate_fwd_bwd"] = {"error": repr(ex)}
         if multi:
             line["extra"] = dist_extra
+            line["per_rank"] = state.get("per_rank")
+            line["roofline"]["per_rank_frac_gather_model"] = (state.get("per_rank") or {}).get("spmm_frac_gather_model")
         line.setdefault("extra", {})["c5_full_eval"] = c5_eval
         print(json.dumps(line), flush=True)
 

@@ -28,9 +28,14 @@ class GraphedTrainStep:
 
     def _capture(self, batch):
         self.static_batch = batch.clone()
-        try:
+        import inspect
+        try:                                         # does this optimizer reserve per-capture room for row-lazy tables?
+            takes_steps = len(inspect.signature(self.opt.init_state).parameters) >= 1
+        except (TypeError, ValueError):
+            takes_steps = False
+        if takes_steps:
             self.opt.init_state(self.steps_per_capture)
-        except TypeError:                            # an optimizer without row-lazy tables to reserve for
+        else:                                        # an optimizer without row-lazy tables to reserve for
             self.opt.init_state()
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()

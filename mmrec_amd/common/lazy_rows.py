@@ -226,9 +226,12 @@ class LazyRowEmbedding(nn.Embedding):
         # over the [n, F] gradient); id lists too long for its LDS position list are pre-summed into the owner slots
         presummed = n > MAX_IDS
         if presummed:
-            present = ids >= 0                      # (-1 = "no row": its gradient row is dropped)
+            # no boolean-mask indexing here: `x[mask]` runs nonzero(), a host synchronisation -- illegal inside a hipGraph
+            # capture and a stall in eager mode.  Rows of id -1 ("no row") add zeros into slot 0 instead of being dropped
+            present = ids >= 0
             slots = self._owner.index_select(0, ids.clamp_min(0)).long()
-            g = torch.zeros_like(dY).index_add_(0, slots[present], dY[present])
+            slots = torch.where(present, slots, torch.zeros_like(slots))
+            g = torch.zeros_like(dY).index_add_(0, slots, dY * present.unsqueeze(1).to(dY.dtype))
         else:
             g = dY
         if self._dev is not None:

@@ -114,6 +114,9 @@ class Trainer(AbstractTrainer):
         for batch_idx, interaction in enumerate(train_data):
             if graphed is not None:
                 per_batch.append(graphed(interaction).detach().clone())
+                if (batch_idx + 1) % self.NAN_CHECK_EVERY == 0:      # the same probe as the eager path below
+                    if bool(torch.isnan(torch.stack(per_batch[-self.NAN_CHECK_EVERY:])).any()):
+                        break
                 continue
             self.optimizer.zero_grad()
             replay = interaction.clone() if self.mg else None     # only the Mirror-Gradient variant reuses the batch

