@@ -300,15 +300,17 @@ def vbpr_loss(u_emb, i_emb, raw_feats, w, b, batch, reg_weight):
 # --------------------------------------------------------------------------------------------
 
 
-def full_sort_scores(user_all, item_all, users):
-    """`scores = U[users] @ I^T` -- freedom.py:212-220 and siblings."""
-    return torch.matmul(user_all[torch.as_tensor(users)], item_all.t())
+def full_sort_scores(user_all, item_all, users, out=None):
+    """`scores = U[users] @ I^T` -- freedom.py:212-220 and siblings.  `out`: a buffer to write the block into (walking 50,000
+    users x 500,000 items block by block, fresh 4 GB allocations spend their time in page faults)."""
+    return torch.matmul(user_all[torch.as_tensor(users)], item_all.t(), out=out)
 
 
-def mask_topk(scores, mask, k):
+def mask_topk(scores, mask, k, inplace=False):
     """common/trainer.py:304-309: scores[mask0, mask1] = -1e10 ; topk(k) sorted descending.
-    Returns (values[b,k] fp32, indices[b,k] int64).  Order among exact ties is unspecified."""
-    s = scores.clone()
+    Returns (values[b,k] fp32, indices[b,k] int64).  Order among exact ties is unspecified.  inplace: mask the caller's
+    block itself, as the reference does (trainer.py:307)."""
+    s = scores if inplace else scores.clone()
     m = torch.as_tensor(np.asarray(mask), dtype=torch.int64)
     s[m[0], m[1]] = -1e10
     v, i = torch.topk(s, k, dim=-1)

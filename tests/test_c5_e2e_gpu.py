@@ -220,11 +220,12 @@ def oracle_topk(u_ref, i_ref, users, mask, k, block=2000):
     order = np.argsort(mask[0], kind="stable")
     mr, mc = mask[0][order], mask[1][order]
     vals, idxs = [], []
+    buf = torch.empty(min(block, users.shape[0]), i_ref.shape[0])       # one score block, reused
     for a in range(0, users.shape[0], block):
         z = min(a + block, users.shape[0])
-        s = orc.full_sort_scores(u_ref, i_ref, users[a:z])
+        s = orc.full_sort_scores(u_ref, i_ref, users[a:z], out=buf[:z - a])
         lo, hi = np.searchsorted(mr, a, "left"), np.searchsorted(mr, z, "left")
-        v, i = orc.mask_topk(s, np.stack([mr[lo:hi] - a, mc[lo:hi]]), k)
+        v, i = orc.mask_topk(s, np.stack([mr[lo:hi] - a, mc[lo:hi]]), k, inplace=True)
         vals.append(v), idxs.append(i)
     return torch.cat(vals).numpy(), torch.cat(idxs).numpy()
 
@@ -272,6 +273,21 @@ def check_eval(model, valid_data, u_ref, i_ref, n_sample):
     return idx_np
 
 
+def add_popularity_signal(model):
+    """Evaluation state.  Xavier-initialised tables rank 500K items at random (Recall@20 = 0.0000 on both sides says
+    nothing), and the synthetic graph's only learnable signal is item popularity; so the tables get what a trained model
+    would have learnt of it -- a common direction e0 on every user row and log(1 + degree) of it on every item row --
+    before both sides evaluate the SAME parameters (Recall@20 ~ 0.1, sensitive to the rank order)."""
+    with torch.no_grad():
+        dev = model.user_embedding.weight.device
+        e0 = torch.zeros(model.embedding_dim, device=dev)
+        e0[0] = 1.0
+        deg = torch.bincount(model.edge_indices[1], minlength=model.n_items).float()
+        scale = float(model.item_id_embedding.weight.abs().max())
+        model.user_embedding.weight.add_(scale * e0)
+        model.item_id_embedding.weight.add_(scale * torch.log1p(deg).unsqueeze(1) * e0)
+
+
 def test_freedom_c5_step_and_recall_vs_oracle(tmp_path):
     """config 5 through the plugin (default settings: gathered-rows projection, row-lazy feature tables) and through
     ShardedFREEDOM on a one-rank process group -- one training step and a 50k-user evaluation vs the CPU oracle"""
@@ -291,7 +307,8 @@ def test_freedom_c5_step_and_recall_vs_oracle(tmp_path):
     if lazy_tables:
         for nm in ("image", "text"):
             getattr(model, nm + "_embedding")._pending = []
-    # evaluation: the unpruned graph (freedom.py:212-220)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items() if "embedding" not in k or "user" in k or "item_id" in k}
+    add_popularity_signal(model)
     n = model.n_users + model.n_items
     with torch.no_grad():
         t = time.time()
@@ -301,14 +318,13 @@ def test_freedom_c5_step_and_recall_vs_oracle(tmp_path):
                                            model.item_id_embedding.weight.detach().cpu(), model.n_ui_layers, model.n_layers)
         log("oracle evaluation propagation on the CPU: %.1fs" % (time.time() - t))
     idx_plain = check_eval(model, valid_data, u_ref, i_ref, SHAPE["sample_users"])
-    state = {k: v.detach().clone() for k, v in model.state_dict().items() if "embedding" not in k or "user" in k or "item_id" in k}
     del model
     if USE_GPU:
         torch.cuda.empty_cache()
     # ---- the n_gpus code path: one rank, collectives forced
     if USE_GPU:
         from tests.test_hip_parity import single_rank_rccl_group
-        single_rank_rccl_group(dev)
+        single_rank_rccl_group(torch.device("cuda", torch.cuda.current_device()))
     else:
         import socket
         s = socket.socket()
@@ -329,6 +345,7 @@ def test_freedom_c5_step_and_recall_vs_oracle(tmp_path):
             norm, rnorm = float(g.double().norm()), float(np.linalg.norm(rg.astype(np.float64)))
             assert abs(norm - rnorm) <= 1e-4 * rnorm, (name, norm, rnorm)
         sharded.zero_grad()
+        add_popularity_signal(sharded)
         rows, users, mask, _ = eval_sample(valid_data2, min(4096, SHAPE["sample_users"]))
         sharded.eval()
         idx_sh = sharded.full_sort_topk([users, torch.as_tensor(mask).to(dev)], 50).cpu().numpy()
