@@ -20,6 +20,10 @@ LIB = os.path.join(LIB_DIR, "libmmrec_hip.so")
 SOURCES = ["api.hip", "spmm.hip", "bpr.hip", "infonce.hip", "gemm.hip", "topk.hip", "topk_filter.hip", "graph.hip", "evalsample.hip", "adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
+# per-file extras.  topk_filter.hip: its one-workgroup-per-CU pass kernel reads MFMA results with VALU instructions, which
+# can address the architectural half of the 512-register file only; by default hipcc puts the accumulators of a
+# launch_bounds(256, 1) kernel in the accumulation half and copies every one of them back (v_accvgpr_read per score)
+EXTRA_FLAGS = {"topk_filter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():
@@ -50,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))

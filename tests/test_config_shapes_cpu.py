@@ -8,6 +8,8 @@ from tests._cpu_ops import cpu_ops  # noqa: F401  (fixture)
 from tests.test_config_shapes_gpu import (  # noqa: F401  (collected here without the module's gpu mark)
     test_bm3_step_at_clothing_shape, test_freedom_step_at_sports_shape, test_score_topk_c5_block_vs_oracle,
     test_knn_graph_at_sports_item_count)
+from tests.test_config_shapes_gpu import (  # noqa: F401  (golden at full Amazon-Baby shape: small enough for the CPU stand-ins)
+    test_lattice_step_vs_reference_golden_at_baby_shape, test_mmgcn_step_vs_reference_golden_at_baby_shape)
 
 
 @pytest.fixture(autouse=True)

@@ -362,9 +362,10 @@ def _shapes_golden():
     return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes.npz"), allow_pickle=False))
 
 
-def _check_against_fingerprint(model, g, prefix, tag, cancelling=()):
+def _check_against_fingerprint(model, g, prefix, tag, cancelling=(), loose=()):
     """every gradient against what tests/golden/make_golden_shapes.py recorded from the unmodified reference: Frobenius
-    norm (1e-5), sum, and the recorded rows (whole small tensors)"""
+    norm (1e-5), sum, and the recorded rows (whole small tensors).  `loose`: {name: tolerance} for gradients that are small
+    differences of large sums (stated per test)"""
     for name, p in model.named_parameters():
         key = prefix + "g_" + name
         if key + "_norm" not in g:
@@ -374,13 +375,14 @@ def _check_against_fingerprint(model, g, prefix, tag, cancelling=()):
             assert float(grad.abs().max()) <= 1e-6 * cancelling[name] and g[key + "_norm"] <= 1e-6 * cancelling[name] * 64
             continue
         norm = float(grad.double().norm())
-        assert abs(norm - g[key + "_norm"]) <= 1e-5 * g[key + "_norm"], (tag, name, norm, g[key + "_norm"])
+        tol = loose[name] if name in loose else 1e-5
+        assert abs(norm - g[key + "_norm"]) <= tol * g[key + "_norm"], (tag, name, norm, g[key + "_norm"])
         vals = grad[torch.as_tensor(g[key + "_rows"])] if key + "_rows" in g else grad
         ref = g[key + "_vals"]
-        np.testing.assert_allclose(vals.numpy(), ref, rtol=1e-4, atol=1e-5 * max(float(np.abs(ref).max()), 1e-30),
+        np.testing.assert_allclose(vals.numpy(), ref, rtol=max(1e-4, 10 * tol), atol=tol * max(float(np.abs(ref).max()), 1e-30),
                                    err_msg="%s d%s" % (tag, name))
         scale = g[key + "_norm"] * np.sqrt(grad.numel())
-        assert abs(float(grad.double().sum()) - g[key + "_sum"]) <= 1e-5 * scale, (tag, name, "sum")
+        assert abs(float(grad.double().sum()) - g[key + "_sum"]) <= tol * scale, (tag, name, "sum")
 
 
 def _check_eval_against_golden(model, config, valid_data, g, prefix):
@@ -486,3 +488,81 @@ def test_bm3_step_vs_reference_golden_at_clothing_shape(tmp_path, monkeypatch):
     model.zero_grad()
     model.eval()
     _check_eval_against_golden(model, config, valid_data, g, "bm3_")
+
+
+# ------------------------------------------------------------------------------------------------ LATTICE / MMGCN at Baby shape
+def _baby_models_golden():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baby_models.npz"), allow_pickle=False))
+
+
+def _check_same_init(model, g, prefix):
+    """same seed -> same initial parameters as the reference (make_golden_baby_models.py recorded [:8, :64] of the big ones)"""
+    for name, p in model.named_parameters():
+        ref = g[prefix + "init_" + name]
+        t = p.detach().cpu()
+        if t.dim() == 2 and t.shape[0] * t.shape[1] > (1 << 16):
+            t = t[:8, :64]
+        np.testing.assert_allclose(t.numpy(), ref, rtol=0, atol=0, err_msg="initial " + name)
+
+
+def test_lattice_step_vs_reference_golden_at_baby_shape(tmp_path):
+    """LATTICE (north_star names it) against THE REFERENCE ITSELF at Amazon-Baby shape (tests/golden/baby_models.npz, written by
+    the unmodified reference, seed 999): same initial parameters, same first batch; the graph-building batch of an epoch
+    (lattice.py:137-157: kNN over the projected 7,050 x 64 features, learned + original graph, gradients through image_trs /
+    text_trs / modal_weight) -- 64 rows of the learned item graph, loss, every gradient (norm, sum, sampled rows) -- then the
+    evaluation with the per-evaluate graph rebuild (lattice.py:229-237): the reference Trainer's 16 metrics and sampled
+    top-50 lists.  At this shape the kernels take other plans than on the 200 x 90 golden (long-row chunks in the u-i graph,
+    kNN tiling at 7,050 candidates, the 7,050 x 4096 projection with its split-K slabs)."""
+    g = _baby_models_golden()
+    config, train_data, valid_data, model = build_shape(
+        tmp_path, "LATTICE", "baby", {"reg_weight": 1e-3, "learning_rate": 1e-3, "n_layers": 1, "cf_model": "lightgcn"})
+    dev = model.device
+    _check_same_init(model, g, "lat_")
+    batch = next(iter(train_data))
+    np.testing.assert_array_equal(batch.cpu().numpy(), g["lat_batch"])
+    model.pre_epoch_processing()
+    loss = model.calculate_loss(batch)
+    loss.backward()
+    # the learned item graph: the reference keeps it dense; 64 of its rows
+    dyn, vals = model.item_adj
+    rows = torch.as_tensor(g["lat_item_adj_rows"]).to(dev)
+    sel = torch.isin(dyn.rows, rows)
+    pos = torch.searchsorted(rows, dyn.rows[sel])
+    dense = torch.zeros(rows.numel(), model.n_items, device=dev).index_put((pos, dyn.cols[sel]), vals.detach()[sel], accumulate=True)
+    ref_adj = g["lat_item_adj"]
+    mism = np.abs(dense.cpu().numpy() - ref_adj) > 1e-4 * np.abs(ref_adj).max()
+    assert mism.mean() < 2e-5, mism.mean()          # a near-tied 10th neighbour may differ (fp32 summation order of the sims)
+    np.testing.assert_allclose(float(loss.detach()), float(g["lat_loss"]), rtol=1e-5)
+    _check_against_fingerprint(model, g, "lat_", "LATTICE/baby vs reference")
+    model.zero_grad()
+    model.eval()
+    with torch.no_grad():
+        u, i = model.eval_embeddings()
+    close_scaled(u[torch.as_tensor(g["lat_rows_u"]).to(dev)], g["lat_user_out"], what="user rows vs reference")
+    close_scaled(i[torch.as_tensor(g["lat_rows_i"]).to(dev)], g["lat_item_out"], what="item rows vs reference")
+    _check_eval_against_golden(model, config, valid_data, g, "lat_")
+
+
+def test_mmgcn_step_vs_reference_golden_at_baby_shape(tmp_path):
+    """MMGCN (north_star names it) at Amazon-Baby shape against the unmodified reference model file run on the torch_geometric
+    STAND-IN of tests/golden/_shims (PyG is absent and unpinned in the reference: parity is UNPINNED by construction, SURVEY.md
+    8c -- what this pins is the stand-in's published mean aggregation, index_add / in-degree, mmgcn.py:191-213): the 256 /
+    384 / 64-wide mean aggregations over the 237k-edge graph (spmm_rows_kernel<DCH> with its long-row plan), the 4096 -> 256
+    MLP -- loss, `result` rows, every gradient fingerprint, the evaluation metrics."""
+    g = _baby_models_golden()
+    config, train_data, valid_data, model = build_shape(tmp_path, "MMGCN", "baby", {"reg_weight": 1e-3, "learning_rate": 1e-3})
+    dev = model.device
+    _check_same_init(model, g, "mmg_")
+    np.testing.assert_array_equal(model.id_embedding.detach().cpu()[:8].numpy(), g["mmg_init_id_embedding"])
+    np.testing.assert_array_equal(model.v_gcn.preference.detach().cpu()[:8, :64].numpy(), g["mmg_init_v_preference"])
+    batch = next(iter(train_data))
+    np.testing.assert_array_equal(batch.cpu().numpy(), g["mmg_batch"])
+    loss = model.calculate_loss(batch)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["mmg_loss"]), rtol=1e-5)
+    close_scaled(model.result[torch.as_tensor(g["mmg_result_rows"]).to(dev)], g["mmg_result"], what="result rows vs reference")
+    _check_against_fingerprint(model, g, "mmg_", "MMGCN/baby vs reference (PyG stand-in)")
+    model.zero_grad()
+    model.eval()
+    _check_eval_against_golden(model, config, valid_data, g, "mmg_")

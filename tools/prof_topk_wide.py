@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""A/B of the fp16 top-K filter's pass kernels (topk_filter.hip): the round-2 two-workgroups-per-CU kernel against the
+one-workgroup-per-CU ("wide") kernel in its shapes, per pass.
+
+    python tools/prof_topk_wide.py build      # here (no GPU): variant libraries into tools/probe_libs/
+    python tools/prof_topk_wide.py run        # on the GPU: parity of every variant vs the materialised fp32 path + ms per call
+
+Variants are whole libraries (MMREC_HIP_LIB selects one); `base` = topk_filter.hip of the round-2 tree (git d349f5d)."""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tools", "probe_libs")
+VARIANTS = {          # name -> defines
+    "p1s1": ["-DMMREC_TF_P1S=1"],                 # two-per-CU kernel (v_max3 pass 1, C = -thr dense pass 2), pass 1 on every stage
+    "p1s2": ["-DMMREC_TF_P1S=2"],                 # ... on every 2nd stage
+    "p1s3": ["-DMMREC_TF_P1S=3"],
+    "p1s4": ["-DMMREC_TF_P1S=4"],
+    "wide_p2fr2": ["-DMMREC_TF_WIDE=2", "-DMMREC_TF_FR2=2", "-DMMREC_TF_P1S=1"],
+    "wide_fr4_fr2": ["-DMMREC_TF_WIDE=3", "-DMMREC_TF_FR1=4", "-DMMREC_TF_FR2=2", "-DMMREC_TF_P1S=1"],
+}
+
+
+def build():
+    sys.path.insert(0, ROOT)
+    from mmrec_amd import build as b
+    os.makedirs(OUT, exist_ok=True)
+    b.build(verbose=False)
+    objs = [os.path.join(b.OBJ, s.replace(".hip", ".o")) for s in b.SOURCES if s != "topk_filter.hip"]
+    extra = b.EXTRA_FLAGS.get("topk_filter.hip", [])
+    jobs = [(name, os.path.join(b.CSRC, "topk_filter.hip"), defs + extra) for name, defs in VARIANTS.items()]
+    base_src = os.path.join(b.CSRC, "_topk_filter_r02.hip")
+    with open(base_src, "w") as f:
+        f.write(subprocess.run(["git", "-C", ROOT, "show", "d349f5d:mmrec_amd/csrc/topk_filter.hip"], capture_output=True,
+                               text=True, check=True).stdout)
+    jobs.append(("base", base_src, []))
+    try:
+        for name, src, defs in jobs:
+            o = os.path.join(OUT, "tfw_%s.o" % name)
+            subprocess.check_call([b._hipcc()] + b.FLAGS + defs + ["-c", src, "-o", o])
+            subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                                   os.path.join(OUT, "libmmrec_tfw_%s.so" % name)] + objs + [o])
+            os.remove(o)
+            print("built", name, flush=True)
+    finally:
+        os.remove(base_src)
+
+
+def cases(dev):
+    import numpy as np
+    import torch
+    from mmrec_amd import hip_ops, synth
+    out = []
+    for shape in ("baby", "sports", "clothing"):
+        nu, ni, eu, ei = synth.shaped_edges(shape, seed=0)
+        r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+        g = hip_ops.CsrGraph.from_coo_host(np.stack([r, c]), v, nu + ni, nu + ni, dev, symmetric=True)
+        E0 = torch.empty(nu + ni, 64, device=dev)
+        torch.nn.init.xavier_uniform_(E0[:nu]), torch.nn.init.xavier_uniform_(E0[nu:])
+        E = hip_ops.lightgcn_mean(g, E0, 2)                      # what a model ranks with
+        rp, col = hip_ops.mask_to_csr(np.stack([eu, ei]), nu, dev)
+        out.append((shape, E[:nu].contiguous(), E[nu:].contiguous(), rp, col))
+    gen = torch.Generator(device=dev).manual_seed(9)
+    for nq, nc in ((65536, 500000), (4096, 7050), (20000, 40000), (333, 33000)):
+        common = torch.randn(64, device=dev, generator=gen) * 0.05
+        Q = torch.randn(nq, 64, device=dev, generator=gen) * 0.03 + common
+        C = torch.randn(nc, 64, device=dev, generator=gen) * 0.03 + common
+        mrow = np.repeat(np.arange(nq), 8)
+        mcol = np.random.default_rng(2).integers(0, nc, nq * 8)
+        key = np.unique(mrow.astype(np.int64) * nc + mcol)
+        rp, col = hip_ops.mask_to_csr(np.stack([key // nc, key % nc]), nq, dev)
+        out.append(("%dx%d" % (nq, nc), Q, C, rp, col))
+    return out
+
+
+def run_one():
+    import torch
+    sys.path.insert(0, ROOT)
+    from mmrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    res = []
+    for name, Q, C, rp, col in cases(dev):
+        idx, val = hip_ops.score_topk(Q, C, 50, rp, col, return_values=True)
+        # parity: the materialised fp32 path on a sample of queries (ids up to near-ties: compare the score VALUES)
+        n = min(Q.shape[0], 4096)
+        sel = torch.randperm(Q.shape[0], device=dev, generator=torch.Generator(device=dev).manual_seed(1))[:n].sort()[0]
+        rps = rp.long()
+        lens = (rps[sel + 1] - rps[sel])
+        srp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        srp[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        src = torch.repeat_interleave(rps[sel], lens) + (torch.arange(int(lens.sum()), device=dev) -
+                                                          torch.repeat_interleave(srp[:-1].long(), lens))
+        scol = col[src].contiguous() if src.numel() else col[:1]
+        ridx, rval = hip_ops.score_topk(Q[sel].contiguous(), C, 50, srp, scol, return_values=True, use_filter=False)
+        same_ids = float((idx[sel] == ridx).all(dim=1).float().mean())
+        unit = float(rval.abs().max())
+        dv = float((val[sel] - rval).abs().max()) / max(unit, 1e-30)
+        for _ in range(2):
+            hip_ops.score_topk(Q, C, 50, rp, col)
+        torch.cuda.synchronize()
+        reps = 5 if Q.shape[0] * C.shape[0] > 1e9 else 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hip_ops.score_topk(Q, C, 50, rp, col)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        res.append("%s %.3f ms (ids %.4f, dval %.1e)" % (name, ms, same_ids, dv))
+    print(" | ".join(res))
+
+
+def run():
+    names = ["base"] + list(VARIANTS)
+    for rnd in range(2):
+        for name in names:
+            env = dict(os.environ, MMREC_HIP_LIB=os.path.join(OUT, "libmmrec_tfw_%s.so" % name))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
+            print("%-14s %s" % (name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "FAILED: " + r.stderr[-600:]),
+                  flush=True)
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run, "one": run_one}[sys.argv[1]]()
