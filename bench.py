@@ -243,9 +243,11 @@ def c5_full_eval(dev, rank, world, user_emb, item_emb, eu, ei, n_users, barrier)
     """The second half of BASELINE.json's metric at config-5 size: full-sort evaluation of ALL 1M users against the 500K
     items (train positives masked, top-50), users sharded over the ranks, item table replicated -- no exchange in the data
     path (SURVEY.md 8e "P5 eval: shard users"), so it scales with the GPU count.  Every rank ranks its slice in blocks of
-    50,000 users (the [50,000, 500,000] score block is never formed; the candidate-side preparation of a call -- column
-    means, fp16 copy of the item table -- is per call, 0.56 ms: 17 % of a 20,000-user block); users/s = all users /
-    max-over-ranks time."""
+    65,536 users -- the Trainer's own `hip_eval_batch_size`; 256 query blocks x 16 candidate ranges = exactly 8 rounds of
+    the 512 resident workgroups, where 50,000-user blocks ran 7 rounds for 6.1 rounds of work -- against ONE preparation
+    of the item table (hip_ops.TopkCandidates: column means + centred fp16 copy, 0.56 ms, as the plugins' evaluation does
+    it); the [65,536, 500,000] score block is never formed; users/s = all users / max-over-ranks time (preparation
+    included)."""
     from mmrec_amd import hip_ops
     per = -(-n_users // world)
     lo, hi = min(rank * per, n_users), min((rank + 1) * per, n_users)
@@ -253,14 +255,15 @@ def c5_full_eval(dev, rank, world, user_emb, item_emb, eu, ei, n_users, barrier)
     rp, col = hip_ops.mask_to_csr(np.stack([eu[s:e] - lo, ei[s:e]]), max(hi - lo, 1), dev)
     rp_host = rp.cpu().numpy().astype(np.int64)
     blocks = []
-    for a in range(0, hi - lo, 50_000):
-        b = min(a + 50_000, hi - lo)
+    for a in range(0, hi - lo, 65_536):
+        b = min(a + 65_536, hi - lo)
         blocks.append((a, b, (rp[a:b + 1] - rp[a]).contiguous(), col[rp_host[a]:max(rp_host[b], rp_host[a] + 1)].contiguous()))
 
     def run():
         out = None
+        cands = hip_ops.TopkCandidates(item_emb)
         for a, b, brp, bcol in blocks:
-            out = hip_ops.score_topk(user_emb[lo + a:lo + b], item_emb, 50, brp, bcol)
+            out = hip_ops.score_topk(user_emb[lo + a:lo + b], cands, 50, brp, bcol)
         return out
     run()
     barrier()

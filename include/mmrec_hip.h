@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 6
+#define MMREC_ABI_VERSION 7
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -57,6 +57,11 @@ const char* mmrec_error_string(int err);
  * long_chunk_ptr[n_long+1] (prefix sum of ceil(deg / MMREC_SPMM_CHUNK) per long row).  Each chunk
  * is reduced by one workgroup into `partials` (n_chunks x 64 fp32 workspace) and the chunks of a row
  * are then summed in order -- deterministic, no float atomics.  partials = n_chunks * d floats.
+ * long_tickets (ABI 7; may be NULL): n_long int32 counters, ZERO before the first call and left at zero by every call.
+ * With them, graphs of at most MMREC_SPMM_FUSED_REDUCE_MAX_ROWS rows finish a multi-chunk row inside the launch (the chunk
+ * block that arrives last sums the partials, in the same order: same bits) instead of in a second launch -- these graphs
+ * are cache resident and latency bound (Amazon-Baby: 18.5 -> 14 us per layer).  One graph's tickets / partials must not be
+ * used by two launches at the same time.
  *
  * Epilogue per row r (y = alpha * sum + beta * Z[r], Z may be NULL):
  *      Y[r] = y                         (Y may be NULL when only the running sum is wanted)
@@ -66,6 +71,7 @@ const char* mmrec_error_string(int err);
 #ifndef MMREC_SPMM_CHUNK
 #define MMREC_SPMM_CHUNK 512            /* nnz per long-row chunk (one workgroup) */
 #endif
+#define MMREC_SPMM_FUSED_REDUCE_MAX_ROWS (1 << 18)
 #define MMREC_SPMM_LONG_ROW_DEFAULT 32  /* long_row_threshold of HBM-sized graphs; cache-resident ones (<= 2^18 columns) run
                                           * 30 % faster with 16: mmrec_amd/hip_ops.py default_long_row_threshold */
 
@@ -74,7 +80,7 @@ int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float
                        int32_t n_rows, int32_t d, float alpha, float beta, float acc_scale,
                        int32_t long_row_threshold, const int32_t* long_rows,
                        const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
-                       float* partials, mmrec_stream_t stream);
+                       float* partials, int32_t* long_tickets, mmrec_stream_t stream);
 
 /* One LayerGCN layer in one launch (layergcn.py:131-135): y = A x ; w[row] = cosine_similarity(y[row], ego[row]) with
  * eps 1e-8 per norm ; scaled = w * y (the next layer's input) ; acc_out = acc_in + scaled (acc_in NULL: acc_out = scaled;
@@ -84,7 +90,7 @@ int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t* colidx, co
                                 float* Y, const float* ego, float* scaled, float* w, const float* acc_in,
                                 float* acc_out, int32_t n_rows, int32_t d, int32_t long_row_threshold,
                                 const int32_t* long_rows, const int32_t* long_chunk_ptr, int32_t n_long,
-                                int32_t n_chunks, float* partials, mmrec_stream_t stream);
+                                int32_t n_chunks, float* partials, int32_t* long_tickets, mmrec_stream_t stream);
 /* Host-side plan helpers (pure CPU, rowptr is a HOST pointer).  count: returns n_long and n_chunks;
  * fill: writes long_rows[n_long] and long_chunk_ptr[n_long+1] (host arrays the caller copies to the
  * device).  partials workspace = n_chunks * 64 * 4 bytes. */
@@ -201,6 +207,18 @@ int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc,
                          const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
                          int64_t* out_idx, float* out_val, void* workspace, int32_t flags,
                          mmrec_stream_t stream);
+/* Several query blocks against the SAME candidate table (ABI 7) -- the batches of one evaluation and its valid / test pair
+ * (trainer.py:262,271,298-310: the item table is frozen while evaluating): the candidate side of the fp16 filter (column
+ * means, centred fp16 copy of C, its norms: 0.56 ms at 500K candidates, 8 % of a 65,536-query block) is computed once into
+ * a caller-owned buffer of mmrec_topk_prepared_bytes(nc, kd) bytes (0: the filter does not serve this (nc, kd); use
+ * mmrec_score_topk_f32) and handed to every call.  The buffer is valid as long as C is unchanged; same results as
+ * mmrec_score_topk_f32 bit for bit.  `C` itself is still needed: the exact refinement reads the fp32 rows. */
+size_t mmrec_topk_prepared_bytes(int32_t nc, int32_t kd);
+int mmrec_topk_prepare_f32(const float* C, int32_t nc, int32_t kd, void* prepared, mmrec_stream_t stream);
+int mmrec_score_topk_prepared_f32(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
+                                  int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
+                                  int64_t* out_idx, float* out_val, void* workspace, int32_t flags,
+                                  mmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * P1  graph build on device.

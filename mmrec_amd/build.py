@@ -20,10 +20,7 @@ LIB = os.path.join(LIB_DIR, "libmmrec_hip.so")
 SOURCES = ["api.hip", "spmm.hip", "bpr.hip", "infonce.hip", "gemm.hip", "topk.hip", "topk_filter.hip", "graph.hip", "evalsample.hip", "adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
-# per-file extras.  topk_filter.hip: its one-workgroup-per-CU pass kernel reads MFMA results with VALU instructions, which
-# can address the architectural half of the 512-register file only; by default hipcc puts the accumulators of a
-# launch_bounds(256, 1) kernel in the accumulation half and copies every one of them back (v_accvgpr_read per score)
-EXTRA_FLAGS = {"topk_filter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {}    # per-file extras: {source name: [flags]}
 
 
 def _hipcc():

@@ -53,6 +53,25 @@ __device__ __forceinline__ T ld_stream(const T* p) {
     return (MMREC_SPMM_LAB & 1) ? __builtin_nontemporal_load(p) : *p;
 }
 
+// Partial sums that another workgroup of the SAME launch reads (the last-arriver row finish below): written and read with
+// agent-scope accesses (sc1: through the XCD's L2 to the device's coherence point), so that no L2 write-back /
+// invalidate fence is needed -- an agent-scope release fence writes back the whole L2 (measured 2.3 x on a kernel that did
+// one per wave).
+__device__ __forceinline__ void st_coherent(float4* p, float4 v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_coherent(const float4* p) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float4*>(p));
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
+
 // Embedding rows are d = 64 * DCH floats (DCH = 1 for every d = 64 graph model; 4 and 6 for MMGCN's
 // 256- and 384-wide modality layers): a 16-lane group walks a row in DCH chunks of 16 x float4.
 struct RowEpilogue {
@@ -139,6 +158,36 @@ __device__ __forceinline__ void gather_span(const int32_t* __restrict__ colidx,
     }
 }
 
+// Sum of the chunk partials [c0, c1) of one long row by a whole workgroup: group g sums chunks g, g + 16, ... in order, then
+// a fixed-order LDS tree over the 16 groups (the heaviest C5 row has 280 chunks; a single sequential chain over them
+// would cost ~110 us); group 0 finishes the row.  ONE order for both callers -- the reduce kernel and the last-arriver
+// chunk block -- so the two forms give the same bits.
+template <int DCH, bool COHERENT>
+__device__ __forceinline__ void reduce_long_row(const float* __restrict__ partials, int c0, int c1, int row,
+                                                const RowEpilogue& ep, float4 (*red)[16 * DCH]) {
+    const int lane16 = threadIdx.x & 15, g = threadIdx.x >> 4;
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) {
+        float4 t = f4_zero();
+        for (int c = c0 + g; c < c1; c += 16) {
+            const float4* src = reinterpret_cast<const float4*>(partials) + (size_t)c * (16 * DCH) + ch * 16 + lane16;
+            t = f4_add(t, COHERENT ? ld_coherent(src) : *src);
+        }
+        red[g][ch * 16 + lane16] = t;
+    }
+    __syncthreads();
+    if (g == 0) {
+        float4 r[DCH];
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            r[ch] = red[0][ch * 16 + lane16];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) r[ch] = f4_add(r[ch], red[k][ch * 16 + lane16]);
+        }
+        store_row<DCH>(ep, row, lane16, r);
+    }
+}
+
 // One launch covers both kinds of work: blocks [0, n_chunks) reduce one long-row chunk each (started
 // first: they are the longest dependency chains), blocks [n_chunks, ...) process 64 short rows each.
 template <int DCH>
@@ -147,8 +196,9 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
     const float* __restrict__ vals, const float* __restrict__ X, RowEpilogue ep, int n_rows,
     int long_t, int rows_per_group, const int32_t* __restrict__ long_rows,
     const int32_t* __restrict__ long_chunk_ptr, int n_long, int n_chunks,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, int32_t* __restrict__ tickets) {
     __shared__ float4 red[16][16 * DCH];
+    __shared__ int s_last;
     const int lane16 = threadIdx.x & 15;
     const int g = threadIdx.x >> 4;
     const float4* X4 = reinterpret_cast<const float4*>(X);
@@ -182,10 +232,30 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
                 store_row<DCH>(ep, row, lane16, t);  // the whole row fitted one chunk: done
             } else {
 #pragma unroll
-                for (int ch = 0; ch < DCH; ++ch)
-                    reinterpret_cast<float4*>(partials)[(size_t)chunk * (16 * DCH) + ch * 16 + lane16] = t[ch];
+                for (int ch = 0; ch < DCH; ++ch) {
+                    float4* dst = reinterpret_cast<float4*>(partials) + (size_t)chunk * (16 * DCH) + ch * 16 + lane16;
+                    if (tickets) st_coherent(dst, t[ch]); else *dst = t[ch];
+                }
             }
         }
+        // `tickets` (small, latency-bound graphs): the row is finished HERE by the chunk block that arrives last, instead of
+        // by a second launch (4.5 us of a 19 us Amazon-Baby layer for the 15 rows that span several chunks).  The partial
+        // was written at agent scope; the wave that wrote it waits for the acknowledgement and takes a ticket; the block
+        // holding the last ticket reads all partials at agent scope in the reduce kernel's order (same bits) and leaves
+        // the ticket at zero for the next launch.
+        const int c0 = long_chunk_ptr[lo], c1 = long_chunk_ptr[lo + 1];
+        if (!tickets || c1 - c0 == 1) return;     // uniform
+        if (threadIdx.x < 64) {                    // the wave of group 0
+            __builtin_amdgcn_s_waitcnt(0);         // my partial is out (vmcnt(0))
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (threadIdx.x == 0)
+                s_last = __hip_atomic_fetch_add(tickets + lo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c1 - c0 - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;                       // uniform
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        reduce_long_row<DCH, true>(partials, c0, c1, row, ep, red);
+        if (threadIdx.x == 0) __hip_atomic_store(tickets + lo, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const int row0 = ((int)blockIdx.x - n_chunks) * 16 * rows_per_group + g;
@@ -203,9 +273,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
     }
 }
 
-// One workgroup per long row that spans several chunks: group g sums chunks g, g+16, ... in order,
-// then a fixed-order LDS tree over the 16 groups (the heaviest C5 row has 280 chunks; a single
-// sequential chain over them would cost ~110 us).  Single-chunk rows were finished by their chunk block.
+// One workgroup per long row that spans several chunks (the two-launch form: large graphs).
 template <int DCH>
 __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(
     const int32_t* __restrict__ long_rows, const int32_t* __restrict__ long_chunk_ptr, int n_long,
@@ -213,36 +281,18 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(
     __shared__ float4 red[16][16 * DCH];
     const int i = blockIdx.x;
     const int c0 = long_chunk_ptr[i], c1 = long_chunk_ptr[i + 1];
-    if (c1 - c0 <= 1) return;  // uniform for the block
-    const int lane16 = threadIdx.x & 15, g = threadIdx.x >> 4;
-#pragma unroll
-    for (int ch = 0; ch < DCH; ++ch) {
-        float4 t = f4_zero();
-        for (int c = c0 + g; c < c1; c += 16)
-            t = f4_add(t, reinterpret_cast<const float4*>(partials)[(size_t)c * (16 * DCH) + ch * 16 + lane16]);
-        red[g][ch * 16 + lane16] = t;
-    }
-    __syncthreads();
-    if (g == 0) {
-        float4 r[DCH];
-#pragma unroll
-        for (int ch = 0; ch < DCH; ++ch) {
-            r[ch] = red[0][ch * 16 + lane16];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) r[ch] = f4_add(r[ch], red[k][ch * 16 + lane16]);
-        }
-        store_row<DCH>(ep, long_rows[i], lane16, r);
-    }
+    if (c1 - c0 <= 1) return;  // uniform for the block: single-chunk rows were finished by their chunk block
+    reduce_long_row<DCH, false>(partials, c0, c1, long_rows[i], ep, red);
 }
 
 template <int DCH>
 void launch_spmm(hipStream_t s, int blocks, int nch, const int32_t* rowptr, const int32_t* colidx,
                  const float* vals, const float* X, const RowEpilogue& ep, int n_rows, int long_t,
                  int rows_per_group, const int32_t* long_rows, const int32_t* long_chunk_ptr, int n_long,
-                 float* partials) {
+                 float* partials, int32_t* tickets) {
     hipLaunchKernelGGL(spmm_rows_kernel<DCH>, dim3(blocks + nch), dim3(256), 0, s, rowptr, colidx, vals, X,
-                       ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, nch, partials);
-    if (n_long > 0 && nch > n_long)  // at least one row spans several chunks
+                       ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, nch, partials, tickets);
+    if (!tickets && n_long > 0 && nch > n_long)  // at least one row spans several chunks
         hipLaunchKernelGGL(spmm_long_reduce_kernel<DCH>, dim3(n_long), dim3(256), 0, s, long_rows,
                            long_chunk_ptr, n_long, partials, ep);
 }
@@ -305,7 +355,7 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
                                   float* acc_out, int32_t n_rows, int32_t d, float alpha, float beta,
                                   float acc_scale, int32_t long_row_threshold,
                                   const int32_t* long_rows, const int32_t* long_chunk_ptr,
-                                  int32_t n_long, int32_t n_chunks, float* partials,
+                                  int32_t n_long, int32_t n_chunks, float* partials, int32_t* long_tickets,
                                   mmrec_stream_t stream) {
     if (d <= 0 || d % MMREC_EMB_DIM || d / MMREC_EMB_DIM > 6) return MMREC_ERR_UNSUPPORTED;
     if (n_rows < 0 || n_long < 0 || n_chunks < 0 || long_row_threshold < 0) return MMREC_ERR_BAD_ARG;
@@ -323,10 +373,13 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     // without a plan every row goes through the row kernel
     const int long_t = n_long > 0 ? long_row_threshold : INT32_MAX;
     const int nch = n_long > 0 ? n_chunks : 0;
+    // rows finished inside the launch (last-arriver) on the small, latency-bound graphs only: a large graph has
+    // thousands of multi-chunk rows and is bandwidth bound; its second launch costs nothing measurable
+    int32_t* tickets = (n_long > 0 && n_rows <= MMREC_SPMM_FUSED_REDUCE_MAX_ROWS) ? long_tickets : nullptr;
 #define MMREC_SPMM_CASE(D)                                                                               \
     case D:                                                                                              \
         launch_spmm<D>(s, blocks, nch, rowptr, colidx, vals, X, ep, n_rows, long_t, rows_per_group,      \
-                       long_rows, long_chunk_ptr, n_long, partials);                                     \
+                       long_rows, long_chunk_ptr, n_long, partials, tickets);                            \
         break;
     switch (d / MMREC_EMB_DIM) {
         MMREC_SPMM_CASE(1) MMREC_SPMM_CASE(2) MMREC_SPMM_CASE(3) MMREC_SPMM_CASE(4) MMREC_SPMM_CASE(5)
@@ -344,7 +397,7 @@ extern "C" int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t*
                                            const float* acc_in, float* acc_out, int32_t n_rows, int32_t d,
                                            int32_t long_row_threshold, const int32_t* long_rows,
                                            const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
-                                           float* partials, mmrec_stream_t stream) {
+                                           float* partials, int32_t* long_tickets, mmrec_stream_t stream) {
     if (d != MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
     if (n_rows < 0 || n_long < 0 || n_chunks < 0 || long_row_threshold < 0) return MMREC_ERR_BAD_ARG;
     if (n_rows == 0) return 0;
@@ -357,8 +410,9 @@ extern "C" int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t*
     const int blocks = (n_rows + 16 * rows_per_group - 1) / (16 * rows_per_group);
     const int long_t = n_long > 0 ? long_row_threshold : INT32_MAX;
     const int nch = n_long > 0 ? n_chunks : 0;
+    int32_t* tickets = (n_long > 0 && n_rows <= MMREC_SPMM_FUSED_REDUCE_MAX_ROWS) ? long_tickets : nullptr;
     launch_spmm<1>(s, blocks, nch, rowptr, colidx, vals, X, ep, n_rows, long_t, rows_per_group, long_rows,
-                   long_chunk_ptr, n_long, partials);
+                   long_chunk_ptr, n_long, partials, tickets);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

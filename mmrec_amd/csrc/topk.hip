@@ -622,10 +622,21 @@ extern "C" size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd,
     return b;
 }
 
-extern "C" int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc,
-                                    int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col,
-                                    int32_t k, int64_t* out_idx, float* out_val, void* workspace,
-                                    int32_t flags, mmrec_stream_t stream) {
+extern "C" size_t mmrec_topk_prepared_bytes(int32_t nc, int32_t kd) {
+    // the fp16 filter's candidate side; 0 = no shape of this (nc, kd) is served by it
+    return (nc > 0 && topk64_filter_applicable(1, nc, kd, 1)) ? topk64_filter_prepared_bytes(nc) : 0;
+}
+
+extern "C" int mmrec_topk_prepare_f32(const float* C, int32_t nc, int32_t kd, void* prepared, mmrec_stream_t stream) {
+    if (!C || !prepared || nc <= 0) return MMREC_ERR_BAD_ARG;
+    if (!topk64_filter_applicable(1, nc, kd, 1)) return MMREC_ERR_UNSUPPORTED;
+    return topk64_filter_prepare(C, nc, prepared, mmrec_stream(stream));
+}
+
+static int score_topk_impl(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
+                           int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col,
+                           int32_t k, int64_t* out_idx, float* out_val, void* workspace,
+                           int32_t flags, mmrec_stream_t stream) {
     if (nq < 0 || nc < 0 || kd <= 0 || (kd & 3)) return MMREC_ERR_UNSUPPORTED;
     if (flags & ~MMREC_TOPK_NO_FILTER) return MMREC_ERR_BAD_ARG;
     if (k <= 0 || k > MMREC_TOPK_MAX || k > nc) return MMREC_ERR_BAD_ARG;
@@ -637,7 +648,7 @@ extern "C" int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, 
     char* ws = static_cast<char*>(workspace);
     hipStream_t s = mmrec_stream(stream);
     if (p.materialise && !(flags & MMREC_TOPK_NO_FILTER) && topk64_filter_applicable(nq, nc, kd, k))
-        return topk64_filter_launch(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, s);
+        return topk64_filter_launch(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
     if (p.materialise) {
         float* Ct = nullptr;
         if (kd == 64) {
@@ -702,4 +713,19 @@ extern "C" int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, 
         hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(64), 0, s, tmp_idx, tmp_val, nq, k,
                            p.n_split, out_idx, out_val);
     MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc,
+                                    int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col,
+                                    int32_t k, int64_t* out_idx, float* out_val, void* workspace,
+                                    int32_t flags, mmrec_stream_t stream) {
+    return score_topk_impl(Q, C, nullptr, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, flags, stream);
+}
+
+extern "C" int mmrec_score_topk_prepared_f32(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
+                                             int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col,
+                                             int32_t k, int64_t* out_idx, float* out_val, void* workspace,
+                                             int32_t flags, mmrec_stream_t stream) {
+    if (!prepared) return MMREC_ERR_BAD_ARG;
+    return score_topk_impl(Q, C, prepared, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, flags, stream);
 }

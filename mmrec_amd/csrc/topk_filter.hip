@@ -55,17 +55,8 @@ typedef __attribute__((ext_vector_type(16))) float acc16;
 
 constexpr int F_QWG = 256;     // queries per workgroup: 4 waves x 2 fragments x 32
 constexpr int F_CAPQ = 256;    // survivor slots per query over all ranges
-#ifndef MMREC_TF_WIDE      // bit 0 / bit 1: pass 1 / pass 2 on the one-workgroup-per-CU kernel (filter_pass_wide_kernel); else the
-#define MMREC_TF_WIDE 0    // two-per-CU one (filter_pass_kernel).  tools/prof_topk_wide.py builds the combinations
-#endif
-#ifndef MMREC_TF_P1S       // pass-1 stage stride: 0 = by candidate count (filter_plan), n = forced (tools/prof_topk_wide.py)
+#ifndef MMREC_TF_P1S       // pass-1 stage stride: 0 = by candidate count (filter_plan), n = forced (tools/prof_topk_variants.py)
 #define MMREC_TF_P1S 0
-#endif
-#ifndef MMREC_TF_FR1       // query fragments per wave of the wide kernel in pass 1 / pass 2 (4 or 2)
-#define MMREC_TF_FR1 4
-#endif
-#ifndef MMREC_TF_FR2
-#define MMREC_TF_FR2 2
 #endif
 #ifndef MMREC_TF_MINR      // tools/prof_topk_ranges.py sweeps the number of candidate ranges
 #define MMREC_TF_MINR 8
@@ -141,9 +132,14 @@ __device__ __forceinline__ float fp16_scale(float mx) {
 template <bool CAND>
 __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __restrict__ X, int n, int n_pad,
                                                             const float* __restrict__ stats, uint4* __restrict__ Xs,
-                                                            float* __restrict__ norm, unsigned* __restrict__ maxnorm_key) {
+                                                            float* __restrict__ norm, unsigned* __restrict__ maxnorm_key,
+                                                            int* __restrict__ zero_one, int* __restrict__ zero_rows) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int row = t >> 3, ch = t & 7;   // grid covers n_pad rows exactly (n_pad % 32 == 0)
+    if (!CAND) {   // the call's counters, zeroed on the way (one int, and one int per real row)
+        if (t == 0 && zero_one) *zero_one = 0;
+        if (ch == 0 && row < n && zero_rows) zero_rows[row] = 0;
+    }
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = 0.f;
@@ -423,283 +419,6 @@ __global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The WIDE pass kernel: one workgroup per CU (one wave per SIMD, up to 512 registers), every wave holds FOUR 32-query
-// fragments (512 queries per workgroup), and the per-score VALU work is software-pipelined UNDER the MFMAs instead of
-// running as a burst after them:
-//      stage t:   MFMA(group A, t) || VALU(group B, t-1)   then   MFMA(group B, t) || VALU(group A, t)
-// (group A = fragments 0, 1; group B = fragments 2, 3; 16 MFMAs each).  Why: in the two-workgroups-per-CU kernel above a
-// wave's stage is ds_read -> 16 MFMAs -> wait for the results -> VALU burst -> barrier, and the only cover for the
-// non-MFMA part is the ONE partner wave on the SIMD, whose own MFMA burst needs the same matrix pipe: the passes ran at
-// 38-48 % of the fp16 MFMA rate (profiles/r02_bench_kernel_stats.csv).  A single wave per SIMD has its own VALU work to
-// put between its own MFMAs -- up to ~5 issue slots fit into the 32 cycles of a v_mfma_f32_32x32x16_f16
-// (MI355X_MICROARCH.md) -- and a candidate tile staged in LDS is used by twice as many MFMAs.
-//  * per-score VALU work halved so that it fits those slots:
-//      pass 1: gm = max3(gm, a[r], b[r]): ONE v_max3_f32 per TWO scores (was two v_med3);
-//      pass 2: the accumulators start at -thr (the first MFMA of a chain takes C = a register block holding -thr[query]):
-//              acc = score - thr, so the pass / fail bit is the accumulator's sign bit: ONE v_alignbit per score (was
-//              v_sub + v_alignbit).  The extra rounding of carrying -thr through the fp32 accumulation is <= 2^-22 of
-//              |thr| + sum|q_i c_i| <= 5e-7 |q| max|c'|, inside the slack of eps (1.0e-3 vs the 0.977e-3 the fp16
-//              roundings need).  A fail bit is shifted in per score; the word is inverted once per 32 scores.
-//  * operands of stage t + 1 are read from LDS into a second register set DURING stage t (its tile was made visible by the
-//    barrier that ended stage t - 1), stage t + 2 is written to the other LDS buffer: no LDS latency after the barrier.
-//  * ragged ends: a range's stages are walked in chunks of four with the stage index of every LOAD clamped to the last
-//    real stage: pass 1 sees a candidate twice (a maximum does not care), pass 2 zeroes the words of stages past the end.
-// Same data layouts as above (Qs, Cs, gkeys, bits / word lists): the bound / final / slow kernels do not change.
-constexpr int W_QWG4 = 512, W_QWG2 = 256;   // queries per workgroup of the two shapes below
-
-// FR = 4: four query fragments x one 64-candidate tile pair per stage (512 queries per workgroup; a staged tile feeds
-//         twice the MFMAs; operands of stage t + 1 are read into a second register set during stage t);
-// FR = 2: two query fragments x two tile pairs per stage (256 queries per workgroup, 128 candidates per stage): half the
-//         per-fragment state (16 group maxima / 16 registers of -thr per fragment must sit in architectural VGPRs, which
-//         VALU instructions can address -- 256 of the 512 registers; MFMA sources, the load ring and LDS traffic go through
-//         the accumulation half of the file), twice the LDS reads per MFMA.
-// Group A / B: FR = 4: fragments {0, 1} / {2, 3} on both tiles; FR = 2: both fragments on tiles {a, b} / {c, d}.
-template <bool FILTER, bool SPARSE, int FR>
-__global__ __launch_bounds__(256, 1) void filter_pass_wide_kernel(const PassArgs a) {
-    constexpr int TP = 4 / FR;            // 64-candidate tile pairs per stage
-    constexpr int NT = 2 * TP;            // 32-candidate tiles per stage
-    constexpr int OS = FR == 4 ? 2 : 1;   // operand register sets
-    static_assert(FR == 4 || FR == 2, "two shapes");
-    __shared__ uint4 s_c[2][NT][256];     // [buffer][tile of the stage][row * 8 + swizzled chunk]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * (128 * FR) + wave * (32 * FR);
-    const int t_r0 = blockIdx.y * a.stages_per_range;     // 64-candidate ("small") stages throughout
-    const int t0 = t_r0;
-    const int t1 = min(min(t_r0 + a.stages_per_range, a.n_stages), FILTER ? a.n_stages : a.nc / 64);   // pass 1: whole stages only
-    float gm[FR][16];
-#pragma unroll
-    for (int f = 0; f < FR; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gm[f][r] = -INFINITY;
-    if (t0 < t1) {   // uniform
-    // query fragments: lane (i, h) holds B[k = 32 h + 8 s + j][n = i], i.e. chunk 4 h + s of its query row
-    half8 qf[FR][4];
-    acc16 cinit[FR];         // C operand of a chain's first MFMA: 0 (pass 1) / -thr of the lane's query (pass 2)
-#pragma unroll
-    for (int f = 0; f < FR; ++f) {
-        const int q = q0 + f * 32 + i;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[f][s] = __builtin_bit_cast(half8, a.Qs[(size_t)q * 8 + h * 4 + s]);
-        const float nt = FILTER ? ((q < a.nq) ? -a.thr[q] : -INFINITY) : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cinit[f][r] = nt;
-    }
-    const size_t fstride = (size_t)32 * gridDim.y * 2 * (a.stages_per_range >> 1);    // words between fragments' rows
-    unsigned long long* brow0 = (FILTER && !SPARSE)
-        ? a.bits + (((size_t)(q0 + i) * gridDim.y + blockIdx.y) * 2 + h) * (a.stages_per_range >> 1) : nullptr;
-    // SPARSE: the append in flight per fragment (slot < 0: none)
-    int ps[FR];
-    unsigned pw[FR];
-    unsigned long long pb[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) { ps[f] = -1; pw[f] = 0u; pb[f] = 0ull; }
-    const unsigned wbase = (blockIdx.y * 2 + h) * (a.stages_per_range >> 1);
-    auto commit = [&](int f) __attribute__((always_inline)) {
-        if (ps[f] >= 0 && ps[f] < F_WCAP)
-            a.wlist[(size_t)(q0 + f * 32 + i) * F_WCAP + ps[f]] = make_uint4(pw[f], 0u, (unsigned)pb[f], (unsigned)(pb[f] >> 32));
-        ps[f] = -1;
-    };
-    // stage fill: thread -> (row rr, chunk cc) of every tile
-    const int rr = tid >> 3, cc = tid & 7;
-    const int slot = rr * 8 + (cc ^ ((rr >> 1) & 7));
-    const int sw = (i >> 1) & 7;
-    const int t_last = t1 - 1;
-    uint4 rg0, rg1, rg2, rg3, rg4, rg5, rg6, rg7;   // global -> register ring: four small stages (two tiles each)
-    auto gload = [&](int t, uint4& xa, uint4& xb) __attribute__((always_inline)) {   // small stage t, clamped to the last real one
-        const size_t o = ((size_t)min(t, t_last) * 64 + rr) * 8 + cc;
-        xa = a.Cs[o];
-        xb = a.Cs[o + 32 * 8];
-    };
-    half8 ops[OS][NT][4];        // MFMA A operands: [register set][tile][k step]
-    auto read_tile = [&](auto SET, auto TILE, int buf) __attribute__((always_inline)) {
-        constexpr int set = decltype(SET)::value, tile = decltype(TILE)::value;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ops[set][tile][s] = __builtin_bit_cast(half8, s_c[buf][tile][i * 8 + ((h * 4 + s) ^ sw)]);
-    };
-    acc16 acc[2][2][2];          // [group][fragment of the group][tile of the group]; B's hold the previous stage while A's run
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][fi][0][r] = acc[g][fi][1][r] = FILTER ? 0.f : -INFINITY;
-    unsigned long long bw[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) bw[f] = 0ull;
-    // 16 MFMAs of group G on operand set SET: four chains, k-step major
-    auto mfma_group = [&](auto SET, auto G) __attribute__((always_inline)) {
-        constexpr int set = decltype(SET)::value, g = decltype(G)::value;
-        constexpr int fA = FR == 4 ? 2 * g : 0, tA = FR == 4 ? 0 : 2 * g;    // first fragment / tile of the group
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc[g][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[set][tA][s], qf[fA][s], s == 0 ? cinit[fA] : acc[g][0][0], 0, 0, 0);
-            acc[g][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[set][tA][s], qf[fA + 1][s], s == 0 ? cinit[fA + 1] : acc[g][1][0], 0, 0, 0);
-            acc[g][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[set][tA + 1][s], qf[fA][s], s == 0 ? cinit[fA] : acc[g][0][1], 0, 0, 0);
-            acc[g][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[set][tA + 1][s], qf[fA + 1][s], s == 0 ? cinit[fA + 1] : acc[g][1][1], 0, 0, 0);
-        }
-    };
-    // per-score work of group G on the accumulators it finished last; `live`: the small stage they hold is a real one
-    auto valu_group = [&](auto G, bool live) __attribute__((always_inline)) {
-        constexpr int g = decltype(G)::value;
-        constexpr int fA = FR == 4 ? 2 * g : 0;
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            if (!FILTER) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)   // ONE v_max3_f32 per two scores
-                    gm[fA + fi][r] = __builtin_fmaxf(__builtin_fmaxf(gm[fA + fi][r], acc[g][fi][0][r]), acc[g][fi][1][r]);
-            } else {
-                unsigned w = 0u;   // FAIL bits: sign(score - thr), one v_alignbit_b32 per score
-#pragma unroll
-                for (int r = 0; r < 16; ++r) w = __builtin_amdgcn_alignbit(w, __float_as_uint(acc[g][fi][0][r]), 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) w = __builtin_amdgcn_alignbit(w, __float_as_uint(acc[g][fi][1][r]), 31);
-                w = ~w & (0u - (unsigned)live);      // a stage past the end contributes an empty word (no branch)
-                bw[fA + fi] = (bw[fA + fi] << 32) | w;
-            }
-        }
-    };
-    // two small stages of fragments [F0, F0 + 2) done: word g of their rows
-    auto flush = [&](auto F0, int g) __attribute__((always_inline)) {
-        constexpr int f0 = decltype(F0)::value;
-        if (FILTER && !SPARSE) {
-#pragma unroll
-            for (int f = f0; f < f0 + 2; ++f) brow0[f * fstride + g] = bw[f];   // rows exist up to nq_pad: no per-lane branch
-        }
-        if (FILTER && SPARSE) {
-#pragma unroll
-            for (int f = f0; f < f0 + 2; ++f) {
-                commit(f);   // the previous flush's atomic has long returned
-                if (bw[f] != 0ull && q0 + f * 32 + i < a.nq) {
-                    ps[f] = atomicAdd(a.wcnt + q0 + f * 32 + i, 1);
-                    pw[f] = wbase + (unsigned)g;
-                    pb[f] = bw[f];
-                }
-            }
-        }
-    };
-    auto interleave = [&]() __attribute__((always_inline)) {    // 16 x (1 MFMA, then the VALU work that fits its shadow)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, FILTER ? 5 : 2, 0);
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    if constexpr (FR == 4) {
-        // ---- one small stage per step; ring slot j = (rg[2j], rg[2j+1]) holds stage tb + j; LDS buffer = parity of the stage
-        gload(t0, rg0, rg1);
-        gload(t0 + 1, rg2, rg3);
-        gload(t0 + 2, rg4, rg5);
-        gload(t0 + 3, rg6, rg7);
-        s_c[0][0][slot] = rg0;
-        s_c[0][1][slot] = rg1;
-        s_c[1][0][slot] = rg2;
-        s_c[1][1][slot] = rg3;
-        __syncthreads();
-        read_tile(I0{}, I0{}, 0);
-        read_tile(I0{}, I1{}, 0);
-        __syncthreads();             // stage t0 writes buffer 0 again (stage t0 + 2): every wave has its operands first
-        // stage t on operand set P; (fa, fb): ring slot of stage t (refilled with t + 4), (na, nb): slot of stage t + 2
-        auto stage = [&](int t, auto P, uint4& fa, uint4& fb, const uint4& na, const uint4& nb) __attribute__((always_inline)) {
-            constexpr int p = decltype(P)::value;
-            gload(t + 4, fa, fb);
-            read_tile(std::integral_constant<int, 1 - p>{}, I0{}, 1 - p);     // operands of stage t + 1 (visible since the last barrier)
-            read_tile(std::integral_constant<int, 1 - p>{}, I1{}, 1 - p);
-            mfma_group(P, I0{});
-            valu_group(I1{}, t - 1 >= t0 && t - 1 < t1);
-            interleave();
-            s_c[p][0][slot] = na;      // stage t + 2 -> the buffer stage t was read from (during stage t - 1)
-            s_c[p][1][slot] = nb;
-            mfma_group(P, I1{});
-            valu_group(I0{}, t < t1);
-            interleave();
-            __syncthreads();
-        };
-        for (int tb = t0; tb < t1; tb += 4) {
-            const int g = (tb - t_r0) >> 1;
-            stage(tb, I0{}, rg0, rg1, rg4, rg5);            // ... || VALU(B, tb - 1): completes group B's word g - 1
-            if (tb > t0) flush(I2{}, g - 1);
-            stage(tb + 1, I1{}, rg2, rg3, rg6, rg7);
-            flush(I0{}, g);
-            stage(tb + 2, I0{}, rg4, rg5, rg0, rg1);        // ... || VALU(B, tb + 1): completes group B's word g
-            flush(I2{}, g);
-            stage(tb + 3, I1{}, rg6, rg7, rg2, rg3);
-            flush(I0{}, g + 1);
-        }
-        {   // drain: group B's last stage
-            const int t_end = t0 + ((t1 - t0 + 3) / 4) * 4;
-            valu_group(I1{}, t_end - 1 < t1);
-            flush(I2{}, ((t_end - t_r0) >> 1) - 1);
-        }
-    } else {
-        // ---- two small stages (tiles a, b | c, d) per step; ring slot j = rg[4j .. 4j+3] holds step j of the chunk
-        gload(t0, rg0, rg1);
-        gload(t0 + 1, rg2, rg3);
-        gload(t0 + 2, rg4, rg5);
-        gload(t0 + 3, rg6, rg7);
-        s_c[0][0][slot] = rg0;
-        s_c[0][1][slot] = rg1;
-        s_c[0][2][slot] = rg2;
-        s_c[0][3][slot] = rg3;
-        __syncthreads();
-        // step at small stage t in LDS buffer P; (f0..f3): its ring slot (refilled with t + 4, t + 5), (n0..n3): the next step's
-        auto stage = [&](int t, auto P, uint4& f0, uint4& f1, uint4& f2, uint4& f3, const uint4& n0, const uint4& n1,
-                         const uint4& n2, const uint4& n3) __attribute__((always_inline)) {
-            constexpr int p = decltype(P)::value;
-            gload(t + 4, f0, f1);
-            gload(t + 5, f2, f3);
-            read_tile(I0{}, I0{}, p);
-            read_tile(I0{}, I1{}, p);
-            read_tile(I0{}, I2{}, p);      // (tiles c, d travel under group A's MFMAs)
-            read_tile(I0{}, I3{}, p);
-            mfma_group(I0{}, I0{});
-            valu_group(I1{}, t - 1 >= t0 && t - 1 < t1);       // group B of the previous step: small stage t - 1
-            interleave();
-            if (t > t0) flush(I0{}, ((t - t_r0) >> 1) - 1);    // word of the previous step: (A | B) = small stages t - 2, t - 1
-            s_c[1 - p][0][slot] = n0;      // the next step -> the other buffer (read last during the previous step)
-            s_c[1 - p][1][slot] = n1;
-            s_c[1 - p][2][slot] = n2;
-            s_c[1 - p][3][slot] = n3;
-            mfma_group(I0{}, I1{});
-            valu_group(I0{}, t < t1);
-            interleave();
-            __syncthreads();
-        };
-        for (int tb = t0; tb < t1; tb += 4) {
-            stage(tb, I0{}, rg0, rg1, rg2, rg3, rg4, rg5, rg6, rg7);
-            stage(tb + 2, I1{}, rg4, rg5, rg6, rg7, rg0, rg1, rg2, rg3);
-        }
-        {   // drain: group B of the last step
-            const int t_end = t0 + ((t1 - t0 + 3) / 4) * 4;
-            valu_group(I1{}, t_end - 1 < t1);
-            flush(I0{}, ((t_end - t_r0) >> 1) - 1);
-        }
-    }
-    if (FILTER && SPARSE) {
-#pragma unroll
-        for (int f = 0; f < FR; ++f) commit(f);
-    }
-    }
-    if (!FILTER) {
-#pragma unroll
-        for (int f = 0; f < FR; ++f) {
-            const int q = q0 + f * 32 + i;
-            if (q >= a.nq) continue;
-            unsigned* dst = a.gkeys + (size_t)q * a.n_groups + blockIdx.y * 32 + h * 16;   // 64-B aligned
-#pragma unroll
-            for (int r = 0; r < 16; r += 4)
-                reinterpret_cast<uint4*>(dst)[r >> 2] = make_uint4(f2key(gm[f][r]), f2key(gm[f][r + 1]),
-                                                                   f2key(gm[f][r + 2]), f2key(gm[f][r + 3]));
-        }
-    }
-}
 
 // thr[q] = (k + m)-th largest group maximum - 2 eps_q; queries the filter cannot serve are flagged and
 // get thr = +inf (nothing passes).  One wave per query.
@@ -1047,8 +766,8 @@ inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 inline FilterPlan filter_plan(int nq, int nc) {
     FilterPlan p;
     p.n_stages = cdiv_i(nc, 64);
-    p.qblocks = cdiv_i(nq, MMREC_TF_WIDE ? W_QWG4 : F_QWG);       // (512: either wide shape divides it)
-    p.nq_pad = p.qblocks * (MMREC_TF_WIDE ? W_QWG4 : F_QWG);
+    p.qblocks = cdiv_i(nq, F_QWG);
+    p.nq_pad = p.qblocks * F_QWG;
     // ranges: 8..16 (256..512 group maxima per query), whole groups of 4 stages per range (the register ring; two
     // 64-bit words of pass / fail bits): the most ranges (tightest bound, most head-room for heavily masked queries:
     // k + m must not exceed the number of groups) whose padding stays within 6 % of the least padded split
@@ -1070,7 +789,7 @@ inline FilterPlan filter_plan(int nq, int nc) {
     // stage gives a bound ~2 x as deep in the ranking (~130 survivors, still far from the 256 slots) for half of pass 1
     p.p1_stride = MMREC_TF_P1S > 0 ? MMREC_TF_P1S : (p.sparse ? 2 : 1);
     p.bits_bytes = p.sparse ? ((((size_t)nq * 4 + 255) & ~(size_t)255) + (size_t)nq * F_WCAP * 16)
-                            : (size_t)((MMREC_TF_WIDE & 2) ? p.nq_pad : nq) * p.R * p.spr * 8;   // wide: rows of the padding queries too
+                            : (size_t)nq * p.R * p.spr * 8;
     return p;
 }
 inline size_t al256f(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1081,24 +800,42 @@ bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
     return kd == 64 && k <= 64 && nc >= F_MIN_NC && nc <= 1000000 && nq >= 1;   // 16-bit ids inside a range
 }
 
+// The candidate side of a call -- column sums / max |c| (stats), the centred fp16 copy Cs and the largest centred row norm
+// -- depends on C only.  A caller that ranks several query blocks against the SAME table (the batches of one evaluation and
+// its valid / test pair, trainer.py:298-310: weights are frozen) prepares it once (`prepared`: 512 B of statistics + Cs) and
+// hands it to every call; without it a call prepares its own copy inside its workspace.
+size_t topk64_filter_prepared_bytes(int nc) {
+    return 512 + al256f((size_t)cdiv_i(nc, 64) * 64 * 128);
+}
+
+int topk64_filter_prepare(const float* C, int nc, void* prepared, hipStream_t s) {
+    const int n_stages = cdiv_i(nc, 64);
+    float* stats = static_cast<float*>(prepared);          // [0..63] column sums of C, [65] max |c| key, [66] max |c'| key
+    uint4* Cs = reinterpret_cast<uint4*>(static_cast<char*>(prepared) + 512);
+    hipError_t e = hipMemsetAsync(stats, 0, 512, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, stats);
+    hipLaunchKernelGGL((filter_convert_kernel<true>), dim3(n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc, n_stages * 64,
+                       stats, Cs, (float*)nullptr, reinterpret_cast<unsigned*>(stats) + 66, (int*)nullptr, (int*)nullptr);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
 size_t topk64_filter_workspace_bytes(int nq, int nc, int k) {
     const FilterPlan p = filter_plan(nq, nc);
-    return al256f((size_t)p.nq_pad * 128) + al256f((size_t)p.n_stages * 64 * 128) + al256f((size_t)p.nq_pad * 4) + 512 +
+    return al256f((size_t)p.nq_pad * 128) + topk64_filter_prepared_bytes(nc) + al256f((size_t)p.nq_pad * 4) + 256 +
            al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f(p.bits_bytes) +
            al256f((size_t)F_SLOW_PARTS * 64 * 8);
 }
 
 int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,
                          const int32_t* mask_col, int k, int64_t* out_idx, float* out_val, void* workspace,
-                         hipStream_t s) {
+                         const void* prepared, hipStream_t s) {
     const FilterPlan p = filter_plan(nq, nc);
     char* ws = static_cast<char*>(workspace);
     uint4* Qs = reinterpret_cast<uint4*>(ws);          ws += al256f((size_t)p.nq_pad * 128);
-    uint4* Cs = reinterpret_cast<uint4*>(ws);          ws += al256f((size_t)p.n_stages * 64 * 128);
+    char* own = ws;                                    ws += topk64_filter_prepared_bytes(nc);   // used when `prepared` is null
     float* qnorm = reinterpret_cast<float*>(ws);       ws += al256f((size_t)p.nq_pad * 4);
-    float* stats = reinterpret_cast<float*>(ws);       // [0..63] column sums of C, [65] max |c| key,
-    unsigned* cmax = reinterpret_cast<unsigned*>(ws) + 66;   // [66] max |c'| key, [67] length of the slow queue
-    int* n_flagged = reinterpret_cast<int*>(ws) + 67;  ws += 512;
+    int* n_flagged = reinterpret_cast<int*>(ws);       ws += 256;                                // length of the slow queue
     unsigned* gkeys = reinterpret_cast<unsigned*>(ws); ws += al256f((size_t)nq * p.n_groups * 4);
     float* thr = reinterpret_cast<float*>(ws);         ws += al256f((size_t)nq * 4);
     int* flag = reinterpret_cast<int*>(ws);            ws += al256f((size_t)nq * 4);
@@ -1108,31 +845,23 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     uint4* wlist = reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4));   //         [nq][F_WCAP] entries
     ws += al256f(p.bits_bytes);
     unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][64]
-    hipError_t e = hipMemsetAsync(stats, 0, 512, s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, stats);
-    hipLaunchKernelGGL((filter_convert_kernel<false>), dim3(p.nq_pad * 8 / 256), dim3(256), 0, s, Q, nq, p.nq_pad, stats,
-                       Qs, qnorm, (unsigned*)nullptr);
-    hipLaunchKernelGGL((filter_convert_kernel<true>), dim3(p.n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc,
-                       p.n_stages * 64, stats, Cs, (float*)nullptr, cmax);
-    if (p.sparse) {
-        e = hipMemsetAsync(wcnt, 0, (size_t)nq * 4, s);
-        if (e != hipSuccess) return (int)e;
+    if (!prepared) {
+        const int rc = topk64_filter_prepare(C, nc, own, s);
+        if (rc != 0) return rc;
+        prepared = own;
     }
+    const float* stats = static_cast<const float*>(prepared);
+    const unsigned* cmax = reinterpret_cast<const unsigned*>(prepared) + 66;
+    const uint4* Cs = reinterpret_cast<const uint4*>(static_cast<const char*>(prepared) + 512);
+    // the query-side conversion also zeroes the call's counters (slow-queue length, word-list lengths): no memset launches
+    hipLaunchKernelGGL((filter_convert_kernel<false>), dim3(p.nq_pad * 8 / 256), dim3(256), 0, s, Q, nq, p.nq_pad, stats,
+                       Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
     PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, gkeys, thr, bits, wcnt, wlist};
-    const dim3 grid(p.nq_pad / F_QWG, p.R);
-    const dim3 grid1(p.nq_pad / (128 * MMREC_TF_FR1), p.R), grid2(p.nq_pad / (128 * MMREC_TF_FR2), p.R);   // wide shapes
-    if (MMREC_TF_WIDE & 1)
-        hipLaunchKernelGGL((filter_pass_wide_kernel<false, false, MMREC_TF_FR1>), grid1, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((filter_pass_kernel<false>), grid, dim3(256), 0, s, a);
+    const dim3 grid(p.qblocks, p.R);
+    hipLaunchKernelGGL((filter_pass_kernel<false>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
                        mask_rowptr, qnorm, cmax, stats, thr, flag);
-    if ((MMREC_TF_WIDE & 2) && p.sparse)
-        hipLaunchKernelGGL((filter_pass_wide_kernel<true, true, MMREC_TF_FR2>), grid2, dim3(256), 0, s, a);
-    else if (MMREC_TF_WIDE & 2)
-        hipLaunchKernelGGL((filter_pass_wide_kernel<true, false, MMREC_TF_FR2>), grid2, dim3(256), 0, s, a);
-    else if (p.sparse)
+    if (p.sparse)
         hipLaunchKernelGGL((filter_pass_kernel<true, true>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((filter_pass_kernel<true, false>), grid, dim3(256), 0, s, a);

@@ -105,8 +105,11 @@ class CsrGraph:
                                                 cp.ctypes.data_as(ctypes.c_void_p)), "spmm_plan_fill")
             self.long_rows = torch.from_numpy(lr).to(dev)
             self.long_chunk_ptr = torch.from_numpy(cp).to(dev)
+            # last-arriver counters of the multi-chunk rows (small graphs finish such a row inside the launch): zero now,
+            # left at zero by every launch
+            self.long_tickets = torch.zeros(self.n_long, dtype=torch.int32, device=dev)
         else:
-            self.long_rows = self.long_chunk_ptr = None
+            self.long_rows = self.long_chunk_ptr = self.long_tickets = None
         self._partials = {}
 
     def partials_for(self, d):
@@ -189,7 +192,7 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
                                       _p(acc_in), _p(acc_out), g.n_rows, d, float(alpha),
                                       float(beta), float(acc_scale), g.long_row_threshold,
                                       _p(g.long_rows), _p(g.long_chunk_ptr), g.n_long, g.n_chunks,
-                                      _p(g.partials_for(d)), _stream()), "spmm_csr_f32")
+                                      _p(g.partials_for(d)), _p(g.long_tickets), _stream()), "spmm_csr_f32")
     return Y if Y is not None else acc_out
 
 
@@ -340,7 +343,8 @@ class _LayerGCNSum(torch.autograd.Function):
             _lib.check(lib.mmrec_spmm_csr_f32_layergcn(
                 _p(g.rowptr), _p(g.colidx), _p(g.vals), _p(cur), _p(y), _p(E0), _p(out), _p(w),
                 _p(acc) if layer > 0 else None, _p(acc), g.n_rows, EMB_DIM, g.long_row_threshold, _p(g.long_rows),
-                _p(g.long_chunk_ptr), g.n_long, g.n_chunks, _p(g.partials_for(EMB_DIM)), _stream()), "spmm_layergcn")
+                _p(g.long_chunk_ptr), g.n_long, g.n_chunks, _p(g.partials_for(EMB_DIM)), _p(g.long_tickets), _stream()),
+                "spmm_layergcn")
             ys.append(y), ws.append(w)
             cur = out
         ctx.g, ctx.L = g, L
@@ -741,12 +745,33 @@ def mask_to_csr(mask, n_rows, device):
 TOPK_NO_FILTER = 1
 
 
+class TopkCandidates:
+    """A candidate table [nc, kd] together with the candidate side of the fp16 top-K filter (column means, centred fp16
+    copy, norms: mmrec_topk_prepare_f32), computed ONCE for all the query blocks ranked against it -- the batches of one
+    evaluation and its valid / test pair (trainer.py:262,271,298-310: the item table is frozen while evaluating).
+    `score_topk(Q, TopkCandidates(C), ...)` == `score_topk(Q, C, ...)` bit for bit.  Valid while C is unchanged."""
+
+    def __init__(self, C):
+        lib = _lib.load()
+        self.C = _chk(C.contiguous(), torch.float32, "C", 2)
+        nc, kd = self.C.shape
+        nbytes = lib.mmrec_topk_prepared_bytes(nc, kd)
+        self.prepared = None
+        if nbytes:          # 0: the filter does not serve this shape; calls take the plain entry point
+            self.prepared = _ws(nbytes, self.C.device)
+            _lib.check(lib.mmrec_topk_prepare_f32(_p(self.C), nc, kd, _p(self.prepared), _stream()), "topk_prepare")
+
+
 def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True):
     """top-k over candidates c of <Q[q], C[c]> per query with masked candidates at -1e10; never
     materialises the score matrix.  Returns int64 [nq, k] sorted by score desc (ties: lower id).
+    C: a tensor, or a TopkCandidates (the candidate-side preparation of the fp16 filter done once for many calls).
     use_filter=False keeps the materialised fp32 path where the fp16 filter would serve the call (A/B measurements)."""
     lib = _lib.load()
     Q = _chk(Q.contiguous(), torch.float32, "Q", 2)
+    prepared = None
+    if isinstance(C, TopkCandidates):
+        C, prepared = C.C, (C.prepared if use_filter else None)
     C = _chk(C.contiguous(), torch.float32, "C", 2)
     nq, kd = Q.shape
     nc = C.shape[0]
@@ -760,9 +785,13 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
     idx = torch.empty(nq, k, dtype=torch.int64, device=Q.device)
     val = torch.empty(nq, k, dtype=torch.float32, device=Q.device) if return_values else None
     ws = _ws(lib.mmrec_topk_workspace_bytes(nq, nc, kd, k), Q.device)
-    _lib.check(lib.mmrec_score_topk_f32(_p(Q), _p(C), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
-                                        _p(idx), _p(val), _p(ws), 0 if use_filter else TOPK_NO_FILTER, _stream()),
-               "score_topk")
+    if prepared is not None:
+        _lib.check(lib.mmrec_score_topk_prepared_f32(_p(Q), _p(C), _p(prepared), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
+                                                     _p(idx), _p(val), _p(ws), 0, _stream()), "score_topk_prepared")
+    else:
+        _lib.check(lib.mmrec_score_topk_f32(_p(Q), _p(C), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
+                                            _p(idx), _p(val), _p(ws), 0 if use_filter else TOPK_NO_FILTER, _stream()),
+                   "score_topk")
     return (idx, val) if return_values else idx
 
 

@@ -25,7 +25,7 @@ class FusedEvalMixin:
     _eval_cache = None
 
     def train(self, mode=True):
-        self._eval_cache = None
+        self._eval_cache = self._eval_cands = None
         return super().train(mode)
 
     def eval_embeddings(self):
@@ -40,7 +40,20 @@ class FusedEvalMixin:
             if self.training:
                 return cache
             self._eval_cache = cache
+            self._eval_cands = None
         return self._eval_cache
+
+    _eval_cands = None
+
+    def _cached_eval_candidates(self):
+        """the cached item table with the candidate side of the top-K filter prepared once per evaluation (every batch of
+        the valid AND the test loader ranks against the same frozen table); dropped with the cache"""
+        u, i = self._cached_eval_embeddings()
+        if self.training:
+            return u, i
+        if self._eval_cands is None:
+            self._eval_cands = hip_ops.TopkCandidates(i)
+        return u, self._eval_cands
 
     def full_sort_predict(self, interaction):
         u, i = self._cached_eval_embeddings()
@@ -49,7 +62,8 @@ class FusedEvalMixin:
     @torch.no_grad()
     def full_sort_topk(self, interaction, k):
         users, mask = interaction[0], interaction[1]
-        u, i = self._cached_eval_embeddings()
+        u, cands = self._cached_eval_candidates()
+        i = cands.C if isinstance(cands, hip_ops.TopkCandidates) else cands
         cache = getattr(interaction, 'cache', None)          # our EvalDataLoader: batches never change
         key = ('mask_csr', getattr(interaction, 'cache_key', None), i.shape[0])
         if cache is not None and key in cache:
@@ -58,7 +72,7 @@ class FusedEvalMixin:
             rowptr, cols = mask_to_csr_device(mask, users.shape[0], i.shape[0])
             if cache is not None:
                 cache[key] = (rowptr, cols)
-        return hip_ops.score_topk(u[users].contiguous(), i, k, rowptr, cols)
+        return hip_ops.score_topk(u[users].contiguous(), cands, k, rowptr, cols)
 
 
 class AdjacentTablesMixin:

@@ -405,7 +405,8 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         """every rank ranks its slice of the batch's users; ids all-gathered (no exchange in the scoring itself)"""
         import torch.distributed as tdist
         users, mask = interaction[0], interaction[1]
-        u, i = self._cached_eval_embeddings()
+        u, cands = self._cached_eval_candidates()          # the replicated item table, prepared once per evaluation
+        i = cands.C if isinstance(cands, hip_ops.TopkCandidates) else cands
         rowptr, cols = mask_to_csr_device(mask, users.shape[0], i.shape[0])
         b = users.shape[0]
         per = -(-b // self.world)
@@ -414,7 +415,7 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         if hi > lo:
             rp = rowptr[lo:hi + 1]
             s, e = int(rp[0]), int(rp[-1])
-            out[:hi - lo] = hip_ops.score_topk(u[users[lo:hi]].contiguous(), i, k, (rp - rp[0]).contiguous(),
+            out[:hi - lo] = hip_ops.score_topk(u[users[lo:hi]].contiguous(), cands, k, (rp - rp[0]).contiguous(),
                                                cols[s:max(e, s + 1)].contiguous() if e > s else None)
         if self.world == 1:
             return out[:b]

@@ -198,7 +198,17 @@ def linear(X, W, b=None):
     return F.linear(X, W, b)
 
 
+class TopkCandidates:
+    """hip_ops.TopkCandidates: a candidate table whose filter-side preparation is shared by many calls (here: the table)"""
+
+    def __init__(self, C):
+        _mat(C, "C")
+        self.C, self.prepared = C.contiguous(), None
+
+
 def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True):
+    if isinstance(C, TopkCandidates):
+        C = C.C
     _mat(Q, "Q"), _mat(C, "C", width=Q.shape[1])
     assert Q.shape[1] % 4 == 0, "inner dim %d is not a multiple of 4" % Q.shape[1]
     if mask_rowptr is not None:
@@ -246,7 +256,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "lightgcn_mean", "lightgcn_mean_parts", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

@@ -130,6 +130,70 @@ def test_spmm_row_shards_bitwise_equal(ops, dev):
         assert torch.equal(Yb, Y[r0:r1])
 
 
+@pytest.mark.parametrize("d", [64, 256])
+def test_spmm_last_arriver_row_finish_equals_two_launches(ops, dev, d):
+    """Graphs of <= 2^18 rows finish a multi-chunk row INSIDE the launch (mmrec_spmm_csr_f32 `long_tickets`, ABI 7: the chunk
+    block that arrives last sums the row's partials) instead of in a second launch.  Same summation order => the same bits as
+    the two-launch form (tickets withheld), launch after launch (the tickets are left at zero), in every epilogue -- plain,
+    Z / layer sum, LayerGCN's cosine re-weighting -- and replayed inside a hipGraph.  Amazon-Baby-shaped graph (15 rows
+    span several 512-nonzero chunks) plus rows of 5000 / 1025 / 513 nonzeros."""
+    from mmrec_amd import synth
+    rng = np.random.default_rng(3)
+    nu, ni, eu, ei = synth.shaped_edges("baby", seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    n = nu + ni
+    extra_rows = np.concatenate([np.full(5000, 7), np.full(1025, 9), np.full(513, n - 1)])
+    idx = np.stack([np.concatenate([r, extra_rows]), np.concatenate([c, rng.integers(0, n, extra_rows.shape[0])])])
+    val = np.concatenate([v, rng.standard_normal(extra_rows.shape[0]).astype(np.float32) * 0.01])
+    g = ops.CsrGraph.from_coo_host(idx, val, n, n, dev)
+    assert g.n_chunks > g.n_long > 0 and g.long_tickets is not None
+    X = D((rng.random((n, d), dtype=np.float32) - 0.5) * 0.2, dev)
+    Z = D(rng.standard_normal((n, d)).astype(np.float32), dev)
+    A0 = D(rng.standard_normal((n, d)).astype(np.float32), dev)
+
+    def run(fused):
+        tickets, g.long_tickets = g.long_tickets, (g.long_tickets if fused else None)
+        try:
+            Y, acc = torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
+            ops.spmm_raw(g, X, Y=Y, Z=Z, acc_in=A0, acc_out=acc, alpha=0.5, beta=2.0, acc_scale=0.25)
+            return Y, acc
+        finally:
+            g.long_tickets = tickets
+    ref = run(False)
+    for _ in range(3):
+        got = run(True)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert int(g.long_tickets.abs().sum()) == 0
+    if d == 64:
+        ego = D(rng.standard_normal((n, 64)).astype(np.float32), dev)
+
+        gs = ops.CsrGraph.from_coo_host(idx, val, n, n, dev, symmetric=True)
+        a = ops.layergcn_sum(gs, ego, 2)
+        tickets, gs.long_tickets = gs.long_tickets, None
+        b = ops.layergcn_sum(gs, ego, 2)
+        gs.long_tickets = tickets
+        assert torch.equal(a, b)
+        # replayed as a hipGraph: the tickets reset themselves, nothing comes from the host
+        Y = torch.empty(n, d, device=dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.spmm_raw(g, X, Y=Y)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, stream=side):
+                ops.spmm_raw(g, X, Y=Y)
+        torch.cuda.current_stream().wait_stream(side)
+        Yref = torch.empty_like(Y)
+        tickets, g.long_tickets = g.long_tickets, None
+        ops.spmm_raw(g, X, Y=Yref)
+        g.long_tickets = tickets
+        for _ in range(3):
+            Y.zero_()
+            cg.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(Y, Yref)
+
+
 def test_spmm_empty_and_errors(ops, dev):
     from mmrec_amd._lib import MMRecHipError
     g = ops.CsrGraph.from_coo_host(np.zeros((2, 0), np.int64), np.zeros(0, np.float32), 10, 10, dev)
@@ -694,6 +758,28 @@ def test_topk_filter_word_lists(ops, dev, nq, nc):
     b = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert np.array_equal(a[0].cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("nq,nc", [(700, 7050), (300, 40_037), (100, 3000)])
+def test_topk_prepared_candidates_identical(ops, dev, nq, nc):
+    """mmrec_score_topk_prepared_f32 (ABI 7): the candidate side of the fp16 filter computed ONCE (hip_ops.TopkCandidates)
+    and shared by several query blocks -- the batches of one evaluation, trainer.py:298-310 -- gives the very ids and
+    values of the plain entry point, for every block, in both pass-2 forms (rows of bits / word lists) and for a shape the
+    filter does not serve (no preparation exists: the plain path answers)."""
+    rng = np.random.default_rng(nq * 7 + nc)
+    k = 50
+    Q = D(rng.standard_normal((nq, 64)).astype(np.float32) * 0.2, dev)
+    C = D((rng.standard_normal((nc, 64)) * 0.2 + 0.3).astype(np.float32), dev)
+    key = np.unique(rng.integers(0, nq, 12 * nq).astype(np.int64) * nc + rng.integers(0, nc, 12 * nq))
+    mask = np.stack([key // nc, key % nc])
+    cands = ops.TopkCandidates(C)
+    assert (cands.prepared is not None) == (nc >= 4096)
+    for a, b in ((0, nq), (0, nq // 3), (nq // 3, nq)):
+        sel = (mask[0] >= a) & (mask[0] < b)
+        rp, col = ops.mask_to_csr(np.stack([mask[0][sel] - a, mask[1][sel]]), b - a, dev)
+        plain = ops.score_topk(Q[a:b].contiguous(), C, k, rp, col, return_values=True)
+        prep = ops.score_topk(Q[a:b].contiguous(), cands, k, rp, col, return_values=True)
+        assert torch.equal(plain[0], prep[0]) and torch.equal(plain[1], prep[1])
 
 
 def test_topk_knn_shape(ops, dev, golden):

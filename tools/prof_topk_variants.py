@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""A/B of the fp16 top-K filter's pass kernels (topk_filter.hip): the round-2 two-workgroups-per-CU kernel against the
-one-workgroup-per-CU ("wide") kernel in its shapes, per pass.
+"""A/B of build-time variants of the fp16 top-K filter (topk_filter.hip) as whole libraries (MMREC_HIP_LIB selects one).
 
-    python tools/prof_topk_wide.py build      # here (no GPU): variant libraries into tools/probe_libs/
-    python tools/prof_topk_wide.py run        # on the GPU: parity of every variant vs the materialised fp32 path + ms per call
+    python tools/prof_topk_variants.py build      # here (no GPU): variant libraries into tools/probe_libs/
+    python tools/prof_topk_variants.py run        # on the GPU: parity of every variant vs the materialised fp32 path + ms per call
 
-Variants are whole libraries (MMREC_HIP_LIB selects one); `base` = topk_filter.hip of the round-2 tree (git d349f5d)."""
+`base` = topk_filter.hip of the round-2 tree (git d349f5d).  Round 3 used this harness for the pass-1 stage stride
+(profiles/r03_topk_pass1_stride_ab.log) and for the one-workgroup-per-CU pass kernel that was built, measured and dropped
+(profiles/r03_topk_wide_kernel_ab.log; the kernel itself is in git history: commit "top-K filter: v_max3 group maxima ...")."""
 import os
 import subprocess
 import sys
@@ -14,12 +15,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
-    "p1s1": ["-DMMREC_TF_P1S=1"],                 # two-per-CU kernel (v_max3 pass 1, C = -thr dense pass 2), pass 1 on every stage
-    "p1s2": ["-DMMREC_TF_P1S=2"],                 # ... on every 2nd stage
+    "p1s1": ["-DMMREC_TF_P1S=1"],                 # pass 1 on every stage
+    "p1s2": ["-DMMREC_TF_P1S=2"],                 # ... on every 2nd stage (the default from 32,768 candidates on)
     "p1s3": ["-DMMREC_TF_P1S=3"],
-    "p1s4": ["-DMMREC_TF_P1S=4"],
-    "wide_p2fr2": ["-DMMREC_TF_WIDE=2", "-DMMREC_TF_FR2=2", "-DMMREC_TF_P1S=1"],
-    "wide_fr4_fr2": ["-DMMREC_TF_WIDE=3", "-DMMREC_TF_FR1=4", "-DMMREC_TF_FR2=2", "-DMMREC_TF_P1S=1"],
 }
 
 

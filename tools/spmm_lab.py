@@ -49,13 +49,13 @@ def run(reps):
         fn.restype = ctypes.c_int32
         fn.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         line = []
         for name, b in blocks.items():
             def call():
                 rc = fn(P(b.rowptr), P(b.colidx), P(b.vals), P(x), P(y), None, None, None, b.n_rows, 64, 1.0, 0.0, 1.0,
                         b.long_row_threshold, P(b.long_rows), P(b.long_chunk_ptr), b.n_long, b.n_chunks,
-                        P(b.partials_for(64)), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                        P(b.partials_for(64)), None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
                 assert rc == 0, rc
             for _ in range(3):
                 call()

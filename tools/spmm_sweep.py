@@ -47,7 +47,7 @@ def run():
             fn.restype = ctypes.c_int32
             fn.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                                    ctypes.c_float, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
             out = []
             for thr in (16, 32, 64):
                 nl, nc = ctypes.c_int32(0), ctypes.c_int32(0)
@@ -59,7 +59,7 @@ def run():
 
                 def call(a, b):
                     rc = fn(P(g.rowptr), P(g.colidx), P(g.vals), P(a), P(b), None, None, None, n, 64, 1.0, 0.0, 1.0, thr,
-                            P(lrd), P(cpd), nl.value, nc.value, P(part), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                            P(lrd), P(cpd), nl.value, nc.value, P(part), None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
                     assert rc == 0, rc
                 for _ in range(5):
                     call(x, y)
