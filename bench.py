@@ -93,12 +93,15 @@ def build_c5(dev, rank, world, layout, multi, n_chunks=None):
         n_chunks = int(min(4, max(1, r.shape[0] // max(world, 1) // 1_000_000)))
     sh = BipartiteSharding.from_coo(r, nu, ni, world, n_chunks=n_chunks)
 
+    thr = hip_ops.default_long_row_threshold(nu + ni)        # the unsharded graph's plan, for every block (same summation order)
+
     def make(lr, pc, vals, n_rows, n_cols):
         if isinstance(dev, str) or dev.type != "cuda":       # the CPU stand-in of the block-construction test
-            return hip_ops.CsrGraph.from_coo_host(np.stack([lr, pc]), vals, n_rows, n_cols, dev)
+            return hip_ops.CsrGraph.from_coo_host(np.stack([lr, pc]), vals, n_rows, n_cols, dev, long_row_threshold=thr)
         return hip_ops.CsrGraph.from_coo_device(torch.from_numpy(lr.astype(np.int32)).to(dev),
                                                 torch.from_numpy(pc.astype(np.int32)).to(dev),
-                                                torch.from_numpy(np.ascontiguousarray(vals)).to(dev), n_rows, n_cols)
+                                                torch.from_numpy(np.ascontiguousarray(vals)).to(dev), n_rows, n_cols,
+                                                long_row_threshold=thr)
     ublocks, iblocks = sh.rank_blocks(r, c, v, rank, make)
     return sh, None, ublocks, iblocks, r, c, v
 

@@ -220,6 +220,15 @@ int mmrec_score_topk_prepared_f32(const float* Q, const float* C, const void* pr
                                   int64_t* out_idx, float* out_val, void* workspace, int32_t flags,
                                   mmrec_stream_t stream);
 
+/* Deterministic scatter-add of per-sample gradient rows (ABI 7; config `hip_deterministic`): out[ids[b]] += rows[b], the
+ * occurrences of an id summed in position order by one owner -- no float atomics, so a batch with duplicated ids gives the
+ * same bits run after run (the reference's CPU scatter is deterministic).  `order` = STABLE argsort of ids
+ * (int64[n], the caller sorts); ids < 0 are skipped; d a multiple of 64.  The fused backward kernels (bpr / cosine / infonce /
+ * gather_scale_add) scatter with hardware fp32 atomics: in deterministic mode they are called on the batch's GATHERED rows
+ * with identity ids (every output row is written once) and this entry point does the scatter into the tables. */
+int mmrec_scatter_add_rows_sorted_f32(const int64_t* order, const int64_t* ids, const float* rows, int32_t n, int32_t d,
+                                      float* out, mmrec_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * P1  graph build on device.
  * replaces: get_norm_adj_mat freedom.py:102-126 (structure from de-duplicated train pairs) ;
@@ -355,15 +364,17 @@ int mmrec_adam_rows_step_f32(float* p, float* m, float* v, const int64_t* ids, i
  * step_dev [1] int64 and hyper_dev [2] fp32 are the device scalars mmrec_adam_prepare maintains (step count; lr / (1 -
  * b1^t), 1 / sqrt(1 - b2^t)).  Order inside a step: catchup_dev (before prepare: step_dev = steps taken so far) ...
  * backward ... mmrec_adam_prepare ... hist_set_dev ... rows_step_dev.  hist_set_dev does not write beyond `capacity`
- * entries: it raises *overflow (sticky, device int32) instead, which the host checks between epochs. */
+ * entries: it raises *overflow (sticky, device int32) instead, which the host checks between epochs; from then on
+ * catchup_dev / rows_step_dev (ABI 7: they take the same `capacity`) leave the rows untouched -- there is no table entry to
+ * replay from -- so the run can be resumed from the state before the overflowing step. */
 int mmrec_adam_hist_set_dev(float* hist, int32_t capacity, const int64_t* step_dev, const float* hyper_dev,
                             int32_t* overflow, mmrec_stream_t stream);
 int mmrec_adam_rows_catchup_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, int32_t n_ids,
-                                    int32_t n_rows, int32_t F, int32_t* last_step, const float* hist,
+                                    int32_t n_rows, int32_t F, int32_t* last_step, const float* hist, int32_t capacity,
                                     const int64_t* step_dev, float beta1, float beta2, float eps, float weight_decay,
                                     mmrec_stream_t stream);
 int mmrec_adam_rows_step_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, const float* g,
-                                 int32_t n_ids, int32_t F, int32_t* last_step, const int64_t* step_dev,
+                                 int32_t n_ids, int32_t F, int32_t* last_step, int32_t capacity, const int64_t* step_dev,
                                  const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
                                  int32_t presummed, mmrec_stream_t stream);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mmrec_topk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mmrec_score_topk_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P,
                                        c_int32, _P]),
+    "mmrec_scatter_add_rows_sorted_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P]),
     "mmrec_topk_prepared_bytes": (c_size_t, [c_int32, c_int32]),
     "mmrec_topk_prepare_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),
     "mmrec_score_topk_prepared_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P,
@@ -81,9 +82,9 @@ SIGNATURES = {
     "mmrec_adam_rows_step_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, c_float, c_float,
                                            c_float, c_float, c_float, c_int32, _P]),
     "mmrec_adam_hist_set_dev": (c_int32, [_P, c_int32, _P, _P, _P, _P]),
-    "mmrec_adam_rows_catchup_dev_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_float,
+    "mmrec_adam_rows_catchup_dev_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, c_float,
                                                   c_float, c_float, c_float, _P]),
-    "mmrec_adam_rows_step_dev_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_float, c_float,
+    "mmrec_adam_rows_step_dev_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, c_float, c_float,
                                                c_float, c_float, c_int32, _P]),
 }
 

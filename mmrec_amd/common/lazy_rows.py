@@ -123,6 +123,18 @@ class LazyRowEmbedding(nn.Embedding):
             grown[:self._hist.shape[0]] = self._hist
             self._hist = grown
 
+    @torch.no_grad()
+    def resume(self, n_steps):
+        """State after `load_state_dict` of a checkpoint taken at optimizer step `n_steps`: a checkpoint holds FLUSHED tables
+        (`_save_to_state_dict`), i.e. every row is up to date at that step -- nothing older than it is ever replayed, so
+        only the counters and room for the steps to come are needed."""
+        w = self._state()
+        self._t = int(n_steps)
+        self._last_step.fill_(self._t)
+        if self._hist.shape[0] < self._t + 1024:
+            self._hist = torch.zeros(self._t + 1024, 2, dtype=torch.float32, device=w.device)
+        self._pending, self._prefetched = [], None
+
     def check_overflow(self):
         if self._overflow is not None and int(self._overflow.item()):
             raise _lib.MMRecHipError("row-lazy Adam: more replayed optimizer steps than reserve() made room for; the "
@@ -141,8 +153,8 @@ class LazyRowEmbedding(nn.Embedding):
         if self._dev is not None:
             _lib.check(lib.mmrec_adam_rows_catchup_dev_f32(
                 _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
-                w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), _p(self._dev[0]), b1, b2, eps, wd,
-                _stream()), "adam_rows_catchup_dev")
+                w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._hist.shape[0], _p(self._dev[0]), b1, b2,
+                eps, wd, _stream()), "adam_rows_catchup_dev")
             return
         _lib.check(lib.mmrec_adam_rows_catchup_f32(
             _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
@@ -236,8 +248,9 @@ class LazyRowEmbedding(nn.Embedding):
             g = dY
         if self._dev is not None:
             _lib.check(lib.mmrec_adam_rows_step_dev_f32(_p(w), _p(m), _p(v), _p(ids), _p(self._owner), _p(g), n, w.shape[1],
-                                                        _p(self._last_step), _p(self._dev[0]), _p(self._dev[1]), b1, b2,
-                                                        eps, wd, int(presummed), _stream()), "adam_rows_step_dev")
+                                                        _p(self._last_step), self._hist.shape[0], _p(self._dev[0]),
+                                                        _p(self._dev[1]), b1, b2, eps, wd, int(presummed), _stream()),
+                       "adam_rows_step_dev")
             return True
         _lib.check(lib.mmrec_adam_rows_step_f32(_p(w), _p(m), _p(v), _p(ids), _p(self._owner), _p(g), n, w.shape[1],
                                                 _p(self._last_step), self._t, float(lr), b1, b2, eps, wd, int(presummed),

@@ -66,6 +66,11 @@ class HipAdam(torch.optim.Optimizer):
     def state_dict(self):
         """Under hipGraph replay the host mirror of `step` advances once per CAPTURE, the device counter once per
         replay: the device counter is the truth (a resumed run computes its bias corrections from the saved count)."""
+        for group in self.param_groups:          # a checkpoint holds dense Adam's values: replay what the lazy tables postponed
+            for p in group['params']:
+                table = getattr(p, '_lazy_table', None)
+                if table is not None:
+                    table.flush()
         if self.capturable:
             for group in self.param_groups:
                 if id(group) in self._dev:
@@ -74,6 +79,25 @@ class HipAdam(torch.optim.Optimizer):
                         if p in self.state and self.state[p]:
                             self.state[p]['step'] = n
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """torch restores the moments and the host step counts; the DEVICE step counters of a capturable (hipGraph) optimizer
+        and the row-lazy tables' bookkeeping are restored here, so that a resumed run continues with the bias corrections of
+        step n + 1 (and lazy rows are known to be current at step n: a checkpoint holds flushed tables)."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            n = 0
+            for p in group['params']:
+                st = self.state.get(p)
+                if st and 'step' in st:
+                    st['step'] = int(st['step'])
+                    n = max(n, st['step'])
+            if self.capturable and n:
+                self._group_dev(group)[0].fill_(n)
+            for p in group['params']:
+                table = getattr(p, '_lazy_table', None)
+                if table is not None and p in self.state and self.state[p]:
+                    table.resume(int(self.state[p].get('step', n)))
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -206,9 +206,14 @@ __global__ __launch_bounds__(256) void adam_rows_owner_kernel(const int64_t* __r
 __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
     float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const int64_t* __restrict__ ids,
     int* __restrict__ owner, int F, int* __restrict__ last_step, const float2* __restrict__ hist, int t_now,
-    float beta1, float beta2, float eps, float weight_decay, const long long* __restrict__ step_dev) {
+    float beta1, float beta2, float eps, float weight_decay, const long long* __restrict__ step_dev, int capacity) {
     __shared__ float2 s_h[256];
-    if (step_dev) t_now = (int)step_dev[0];             // graph-replay form: optimizer steps taken so far, from the device
+    if (step_dev) {                                     // graph-replay form: optimizer steps taken so far, from the device
+        t_now = (int)step_dev[0];
+        // a step beyond the scalar table was refused by adam_hist_set_dev_kernel (sticky overflow flag, reported by the host
+        // at the next epoch): there is nothing valid to replay from -- leave the rows as they are, the error stays recoverable
+        if (t_now >= capacity) return;
+    }
     const int64_t row = ids ? ids[blockIdx.x] : (int64_t)blockIdx.x;
     if (row < 0) return;                                // "no row"
     if (ids && owner[row] != (int)blockIdx.x) return;   // a duplicate: the first occurrence does the work
@@ -262,13 +267,14 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(
     float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const int64_t* __restrict__ ids,
     int* __restrict__ owner, const float* __restrict__ g, int n, int F, int* __restrict__ last_step, int t, AdamArgs a,
-    const long long* __restrict__ step_dev, const float* __restrict__ hyper_dev) {
+    const long long* __restrict__ step_dev, const float* __restrict__ hyper_dev, int capacity) {
     // n == 0: g is already summed per owner slot (id lists too long for the LDS position list): only the own position
     extern __shared__ int s_pos[];
     if (step_dev) {                                     // graph-replay form (after adam_prepare_kernel of this step)
         t = (int)step_dev[0];
         a.lr_over_bc1 = hyper_dev[0];
         a.inv_bc2_sqrt = hyper_dev[1];
+        if (t >= capacity) return;                      // no scalar-table entry for this step (overflow flag is up): no half-applied state
     }
     __shared__ int s_wave[4];
     __shared__ int s_total;
@@ -339,7 +345,7 @@ extern "C" int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const i
     if (blocks <= 0) return blocks < 0 ? MMREC_ERR_BAD_ARG : 0;
     hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner, F,
                        last_step, reinterpret_cast<const float2*>(hist), t_now, beta1, beta2, eps, weight_decay,
-                       (const long long*)nullptr);
+                       (const long long*)nullptr, 0);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
@@ -353,30 +359,31 @@ extern "C" int mmrec_adam_hist_set_dev(float* hist, int32_t capacity, const int6
 
 extern "C" int mmrec_adam_rows_catchup_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
                                                int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
-                                               const float* hist, const int64_t* step_dev, float beta1, float beta2,
-                                               float eps, float weight_decay, mmrec_stream_t stream) {
-    if (F <= 0 || (F & 3) || !p || !m || !v || !last_step || !hist || !step_dev) return MMREC_ERR_BAD_ARG;
+                                               const float* hist, int32_t capacity, const int64_t* step_dev, float beta1,
+                                               float beta2, float eps, float weight_decay, mmrec_stream_t stream) {
+    if (F <= 0 || (F & 3) || !p || !m || !v || !last_step || !hist || !step_dev || capacity < 2) return MMREC_ERR_BAD_ARG;
     if (ids && !owner) return MMREC_ERR_BAD_ARG;
     const int blocks = ids ? n_ids : n_rows;
     if (blocks <= 0) return blocks < 0 ? MMREC_ERR_BAD_ARG : 0;
     hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner, F,
                        last_step, reinterpret_cast<const float2*>(hist), 0, beta1, beta2, eps, weight_decay,
-                       reinterpret_cast<const long long*>(step_dev));
+                       reinterpret_cast<const long long*>(step_dev), capacity);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int mmrec_adam_rows_step_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
                                             const float* g, int32_t n_ids, int32_t F, int32_t* last_step,
-                                            const int64_t* step_dev, const float* hyper_dev, float beta1, float beta2,
-                                            float eps, float weight_decay, int32_t presummed, mmrec_stream_t stream) {
-    if (F <= 0 || (F & 3) || n_ids < 0) return MMREC_ERR_BAD_ARG;
+                                            int32_t capacity, const int64_t* step_dev, const float* hyper_dev, float beta1,
+                                            float beta2, float eps, float weight_decay, int32_t presummed,
+                                            mmrec_stream_t stream) {
+    if (F <= 0 || (F & 3) || n_ids < 0 || capacity < 2) return MMREC_ERR_BAD_ARG;
     if (n_ids == 0) return 0;
     if (!p || !m || !v || !ids || !owner || !g || !last_step || !step_dev || !hyper_dev) return MMREC_ERR_BAD_ARG;
     if (!presummed && n_ids > MMREC_ADAM_ROWS_MAX_IDS) return MMREC_ERR_UNSUPPORTED;
     const AdamArgs a{0.f, beta1, beta2, eps, weight_decay, 0.f};
     hipLaunchKernelGGL(adam_rows_step_kernel, dim3(n_ids), dim3(256), presummed ? sizeof(int) : (size_t)n_ids * sizeof(int),
                        mmrec_stream(stream), p, m, v, ids, owner, g, presummed ? 0 : n_ids, F, last_step, 0, a,
-                       reinterpret_cast<const long long*>(step_dev), hyper_dev);
+                       reinterpret_cast<const long long*>(step_dev), hyper_dev, capacity);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
@@ -392,7 +399,7 @@ extern "C" int mmrec_adam_rows_step_f32(float* p, float* m, float* v, const int6
     if (!presummed && n_ids > MMREC_ADAM_ROWS_MAX_IDS) return MMREC_ERR_UNSUPPORTED;     // the position list lives in LDS
     hipLaunchKernelGGL(adam_rows_step_kernel, dim3(n_ids), dim3(256), presummed ? sizeof(int) : (size_t)n_ids * sizeof(int),
                        mmrec_stream(stream), p, m, v, ids, owner, g, presummed ? 0 : n_ids, F, last_step, t, a,
-                       (const long long*)nullptr, (const float*)nullptr);
+                       (const long long*)nullptr, (const float*)nullptr, 0);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

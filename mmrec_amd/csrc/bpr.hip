@@ -269,3 +269,39 @@ extern "C" int mmrec_gather_scale_add_bwd_f32(const float* E, const int64_t* ids
                        mmrec_stream(stream), E, ids, batch, d / 4, coef_scalar, dE);
     MMREC_RETURN_LAUNCH_STATUS();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Deterministic scatter-add of per-sample rows (`hip_deterministic`): out[ids[b]] += rows[b] with the occurrences of an id
+// summed in POSITION order by the one 16-lane group that owns the id's segment of the (stable) sorted order -- no float
+// atomics, so duplicated ids (the same user / item several times in a batch) give the same bits run after run, like the
+// reference's CPU scatter (its CPU path is deterministic).  `order` = stable argsort of ids (the caller sorts:
+// plumbing); ids < 0 are skipped.  Rows of d = 64 k floats.
+namespace {
+__global__ __launch_bounds__(256) void scatter_rows_sorted_kernel(const int64_t* __restrict__ order,
+                                                                  const int64_t* __restrict__ ids,
+                                                                  const float* __restrict__ rows, int n, int d4,
+                                                                  float* __restrict__ out) {
+    const int s = blockIdx.x * 16 + (threadIdx.x >> 4), lane16 = threadIdx.x & 15;
+    if (s >= n) return;
+    const int64_t id = ids[order[s]];
+    if (id < 0 || (s > 0 && ids[order[s - 1]] == id)) return;     // not the head of a segment
+    for (int c = lane16; c < d4; c += 16) {
+        float4 acc = f4_zero();
+        for (int j = s; j < n && ids[order[j]] == id; ++j)
+            acc = f4_add(acc, reinterpret_cast<const float4*>(rows)[(size_t)order[j] * d4 + c]);
+        float4* dst = reinterpret_cast<float4*>(out) + (size_t)id * d4 + c;
+        *dst = f4_add(*dst, acc);
+    }
+}
+}  // namespace
+
+extern "C" int mmrec_scatter_add_rows_sorted_f32(const int64_t* order, const int64_t* ids, const float* rows, int32_t n,
+                                                 int32_t d, float* out, mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    if (n < 0) return MMREC_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!order || !ids || !rows || !out) return MMREC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3((n + 15) / 16), dim3(256), 0, mmrec_stream(stream), order, ids, rows,
+                       n, d / 4, out);
+    MMREC_RETURN_LAUNCH_STATUS();
+}

@@ -55,7 +55,7 @@ typedef __attribute__((ext_vector_type(16))) float acc16;
 
 constexpr int F_QWG = 256;     // queries per workgroup: 4 waves x 2 fragments x 32
 constexpr int F_CAPQ = 256;    // survivor slots per query over all ranges
-#ifndef MMREC_TF_P1S       // pass-1 stage stride: 0 = by candidate count (filter_plan), n = forced (tools/prof_topk_variants.py)
+#ifndef MMREC_TF_P1S       // pass-1 stage stride: 0 = the default of filter_plan (1), n = forced (tools/prof_topk_variants.py)
 #define MMREC_TF_P1S 0
 #endif
 #ifndef MMREC_TF_MINR      // tools/prof_topk_ranges.py sweeps the number of candidate ranges
@@ -784,10 +784,12 @@ inline FilterPlan filter_plan(int nq, int nc) {
     }
     p.n_groups = 32 * p.R;
     p.sparse = nc >= F_SPARSE_NC;
-    // pass 1 on a subset of the candidates: at large candidate counts the two MFMA passes are the call (2 x 3.4 ms of
-    // 8.6 ms per 65,536 x 500,000 block) while the exact refinement of the ~65 survivors per query is 1 % of it; every second
-    // stage gives a bound ~2 x as deep in the ranking (~130 survivors, still far from the 256 slots) for half of pass 1
-    p.p1_stride = MMREC_TF_P1S > 0 ? MMREC_TF_P1S : (p.sparse ? 2 : 1);
+    // pass 1 on a subset of the candidates (every S-th stage) is a probe, not a default.  Measured (profiles/
+    // r03_topk_pass1_stride_ab.log, r03_bench_line_p1s2.json): with i.i.d. embeddings S = 2 takes a 65,536 x 500,000 block from
+    // 8.3 to 6.8 ms (the bound sits ~2 x as deep in the ranking, ~130 survivors per query); with the SMOOTHED embeddings a
+    // propagation produces the scores are packed so densely below the bound that the survivor lists overflow their 256
+    // slots and the queries fall to the exact slow path: the same block took 250 ms.  Correct either way, 30 x slower.
+    p.p1_stride = MMREC_TF_P1S > 0 ? MMREC_TF_P1S : 1;
     p.bits_bytes = p.sparse ? ((((size_t)nq * 4 + 255) & ~(size_t)255) + (size_t)nq * F_WCAP * 16)
                             : (size_t)nq * p.R * p.spr * 8;
     return p;

@@ -206,6 +206,17 @@ class RowShardedOp:
     def __init__(self, entries, local_spmm, group=None, exchange=True):
         self.entries, self.local_spmm, self.group, self.exchange = list(entries), local_spmm, group, exchange
         self.bytes_gathered = 0     # payload this rank RECEIVED through the all-gathers (metrics)
+        if exchange:
+            # The all-gather of a chunk is IN PLACE: the input is the rank's own slot of the output region (what
+            # ncclAllGather documents as sendbuff == recvbuff + rank * sendcount).  Any other overlap of input and output is
+            # undefined for RCCL, so the layout contract is checked here, once, instead of being trusted per call
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            for _, lo, hi, rlo, rhi in self.entries:
+                cb = hi - lo
+                if (rhi - rlo) != world * cb or lo != rlo + rank * cb:
+                    raise ValueError("in-place all-gather contract violated: own rows [%d, %d) are not slot %d of the "
+                                     "region [%d, %d) of %d equal slots" % (lo, hi, rank, rlo, rhi, world))
 
     def apply(self, X, out, Z=None, acc_in=None, acc_out=None, gather_acc=False, write_y=True, **scal):
         """Per entry: Y = out[o], optional Z[o] / acc_in[o] / acc_out[o] slices; the gathered tensor is `acc_out`

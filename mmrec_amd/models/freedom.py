@@ -262,8 +262,12 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
             chunks = int(min(4, max(1, r.shape[0] // self.world // 2_500_000)))
         self.sharding = sh = BipartiteSharding.from_coo(r, nu, ni, self.world, n_chunks=chunks)
         self.nnz_per_rank = sh.nnz_per_rank(r)
+        # ONE long-row plan for every block of the u-i graph, the single-GPU graph's (a function of ITS column count): padded
+        # blocks have N_pad columns and node-order entry blocks n_nodes -- with the per-block default the first and the
+        # later layers could cut rows differently and sum in another order than the unsharded kernel
+        self.ui_threshold = hip_ops.default_long_row_threshold(nu + ni)
         make = lambda lr, pc, vals, n_rows, n_cols: hip_ops.CsrGraph.from_coo_host(  # noqa: E731
-            np.stack([lr, pc]), vals, n_rows, n_cols, self.device)
+            np.stack([lr, pc]), vals, n_rows, n_cols, self.device, long_row_threshold=self.ui_threshold)
         ub, ib = sh.rank_blocks(r, c, v, self.rank, make)
         self.norm_prop = ShardedPropagator(sh, ub, ib, self.rank, _local_spmm, group=self.group, force_collectives=self.force)
         # the same rows with node-order column ids: the first layer reads the replicated parameter table as it is, and
@@ -302,8 +306,9 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         order = np.argsort(idx[0], kind='stable')            # the single-GPU CSR order (transpose() starts from it)
         idx, val = idx[:, order], val[order]
         ipos = sh.items.pos - sh.items.base
+        mm_threshold = hip_ops.default_long_row_threshold(ni)       # the single-GPU item-item graph has n_items columns
         make_i = lambda lr, pc, vals, n_rows, n_cols: hip_ops.CsrGraph.from_coo_host(  # noqa: E731
-            np.stack([lr, pc]), vals, n_rows, n_cols, self.device)
+            np.stack([lr, pc]), vals, n_rows, n_cols, self.device, long_row_threshold=mm_threshold)
         fwd = space_blocks(sh.items, idx[0], idx[1], val, self.rank, ipos, sh.items.size, make_i)
         bwd = space_blocks(sh.items, idx[1], idx[0], val, self.rank, ipos, sh.items.size, make_i)
         self.mm_adj = ShardedSquareMatrix(sh.items, fwd, bwd, self.rank, _local_spmm, group=self.group,
@@ -340,9 +345,10 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         for _, _, lo, hi, _, _ in sh.entries(self.rank):
             sel = (pr >= lo) & (pr < hi)
             lr, vv = (pr[sel] - lo).to(torch.int32).contiguous(), vals[sel].contiguous()
-            blocks.append(hip_ops.CsrGraph.from_coo_device(lr, pc[sel].to(torch.int32).contiguous(), vv, hi - lo, sh.N_pad))
+            blocks.append(hip_ops.CsrGraph.from_coo_device(lr, pc[sel].to(torch.int32).contiguous(), vv, hi - lo, sh.N_pad,
+                                                           long_row_threshold=self.ui_threshold))
             entry.append(hip_ops.CsrGraph.from_coo_device(lr, cols[sel].to(torch.int32).contiguous(), vv, hi - lo,
-                                                          self.n_nodes))
+                                                          self.n_nodes, long_row_threshold=self.ui_threshold))
         nc = sh.n_chunks
         self.masked_prop = ShardedPropagator(sh, blocks[:nc], blocks[nc:], self.rank, _local_spmm, group=self.group,
                                              force_collectives=self.force)
