@@ -431,6 +431,21 @@ def extra_baby(dev):
         out["baby_linear4096_fwd_us"] = dt * 1e6
         out["baby_linear4096_fwd_tflops"] = 2.0 * ni * 4096 * 64 / dt / 1e12
         out["baby_linear4096_fwd_frac_mfma_f32"] = out["baby_linear4096_fwd_tflops"] / MFMA_F32_PEAK_TF
+        # the projection's roofline (north_star: "rocprof MFMA utilisation reported"): FLOP-derived fraction of the fp32-input
+        # MFMA peak measured here, the X bytes it streams, and the COUNTER view (SQ_VALU_MFMA_BUSY_CYCLES over the busy CU
+        # cycles, tools/pmc_kernels.py linear -> profiles/r03_mfma_pmc.json, collected in its own rocprofv3 passes)
+        proj = {"bound": "mfma (fp32 inputs) at the HBM ridge", "peak_tflops": MFMA_F32_PEAK_TF,
+                "baby": {"n": ni, "F": 4096, "fwd_us": dt * 1e6, "fwd_tflops": out["baby_linear4096_fwd_tflops"],
+                         "fwd_frac": out["baby_linear4096_fwd_frac_mfma_f32"], "x_bytes_streamed": 4.0 * ni * 4096,
+                         "x_gbs": 4.0 * ni * 4096 / dt / 1e9}}
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma_pmc.json")))
+            proj["mfma_util_counters"] = {k: {"MfmaUtil_busy_cu": v.get("MfmaUtil_busy_cu"), "duration_us": v.get("duration_ns", 0) / 1e3}
+                                          for k, v in pj.items() if v.get("MfmaUtil_busy_cu")}
+            proj["counters_source"] = "profiles/r03_mfma_pmc.json (committed profile of these kernels, not measured in this run)"
+        except Exception:
+            proj["mfma_util_counters"] = None
+        out["projection_roofline"] = proj
     # forward + backward (dW, db, dX) of the projection, as FREEDOM / BM3 run it every batch
     Xg, Wg, bg = X.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
     G = torch.rand(ni, 64, device=dev, generator=gen) - 0.5
@@ -604,6 +619,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run launches under rocprofv3 for roofline.traffic")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed region and nothing else (no companions, no CPU baseline, no counters): what "
+                         "`rocprofv3 --kernel-trace --stats -- python bench.py --headline-only` profiles, so that the summary's "
+                         "average SpMM duration is the timed launches' (profiles/r03_bench_headline_kernel_stats.csv)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: run the N > 1 code path (process group, sharded blocks, "
@@ -617,6 +636,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group / sharding-plan self-test: no device work, no numbers (runs without a GPU)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_extra = args.no_cpu_baseline = args.no_pmc = True
     if args.pmc_child:
         return pmc_child(args.pmc_child)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -839,6 +860,8 @@ def main():
     # companion at every N: full-sort evaluation of all 1M users at config-5 size, users sharded over the ranks
     c5_eval = None
     try:
+        if args.headline_only:
+            raise RuntimeError("--headline-only")
         ne = nnz_total // 2                       # sym_norm_coo: the first half are the user rows, sorted by (user, item)
         eu_all, ei_all = r[:ne], c[:ne] - sh.n_users
         E = bufs[(N_LAYERS - 1) % 2] if (not multi or args.layout == "allgather") else None
@@ -893,6 +916,8 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                 "ms_per_launch": ms_launch, "launches_timed": int(len(ev)),
                 "alg_bytes_per_launch": float(call_alg.mean()), "achieved_gather_model": alg_gbs,
                 "frac_gather_model": alg_gbs / HBM_PEAK_GBS,
+                # the SURVEY.md 8(d) figure under its own name: (264 B x nnz + 260 B x rows) / mean launch time / 8 TB/s
+                "achieved_8d": alg_gbs, "frac_8d": alg_gbs / HBM_PEAK_GBS,
                 "compulsory_bytes_per_launch": float(call_min.mean()),
                 "frac_compulsory": float(call_min.sum() / (call_ms.sum() * 1e-3) / 1e9) / HBM_PEAK_GBS}
     if traffic is not None:      # headline: what the launch really moves past L2 (<= the fabric can carry: <= 1)

@@ -70,6 +70,10 @@ class Trainer(AbstractTrainer):
         self.fused_eval = True if fused is None else bool(fused)
         dm = config['hip_device_metrics']
         self.device_metrics = True if dm is None else bool(dm)
+        if config['hip_deterministic']:      # new key: bitwise-repeatable training (position-ordered gradient scatters)
+            from mmrec_amd import hip_ops
+            hip_ops.set_deterministic(True)
+            torch.use_deterministic_algorithms(True, warn_only=True)     # the torch ops around the kernels (index_add & co.)
 
     def _build_optimizer(self):
         kinds = {'adam': optim.Adam, 'sgd': optim.SGD, 'adagrad': optim.Adagrad, 'rmsprop': optim.RMSprop}

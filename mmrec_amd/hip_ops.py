@@ -36,6 +36,29 @@ def default_long_row_threshold(n_cols):
 TOPK_MAX = 64
 BPR_LOGSIG, BPR_GAMMA = 0, 1
 
+# `hip_deterministic` (config key; Trainer sets it): the backward scatters of the fused loss kernels (BPR, cosine, InfoNCE,
+# gather-norm) add with hardware fp32 atomics, so a batch with duplicated ids is order-dependent in the last ulp and a
+# training run is not bitwise repeatable, although the reference's CPU path is.  In deterministic mode the same
+# kernels run on the batch's GATHERED rows with identity ids (every output row written once) and the rows are scattered into
+# the tables by mmrec_scatter_add_rows_sorted_f32: duplicates summed in position order by one owner, no atomics.
+DETERMINISTIC = False
+
+
+def set_deterministic(flag=True):
+    global DETERMINISTIC
+    DETERMINISTIC = bool(flag)
+
+
+def scatter_add_rows(ids, rows, out):
+    """out[ids[b]] += rows[b], duplicates summed in position order (deterministic; ids < 0 skipped)"""
+    lib = _lib.load()
+    _chk(ids, torch.int64, "ids", 1)
+    rows, out = _chk(rows.contiguous(), torch.float32, "rows", 2), _chk(out, torch.float32, "out", 2)
+    order = torch.sort(ids, stable=True)[1]
+    _lib.check(lib.mmrec_scatter_add_rows_sorted_f32(_p(order), _p(ids), _p(rows), ids.numel(), rows.shape[1], _p(out),
+                                                     _stream()), "scatter_add_rows_sorted")
+    return out
+
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -413,6 +436,25 @@ def layergcn_sum_parts(g: CsrGraph, parts, n_layers):
 # ------------------------------------------------------------------------------------------------
 # P4  sampled scoring
 # ------------------------------------------------------------------------------------------------
+def _bpr_bwd_deterministic(U, I, users, pos, neg, coef, g, scale, dU, dI):
+    """the fused BPR backward without atomics on the tables: the kernel runs on the gathered rows U[users], I[pos], I[neg]
+    with identity ids (each per-sample gradient row is written once), the rows are then scattered in position order"""
+    lib = _lib.load()
+    B, d = users.numel(), U.shape[1]
+    ar = torch.arange(B, device=U.device)
+    Ug = U.index_select(0, users)
+    Ig = torch.cat((I.index_select(0, pos), I.index_select(0, neg)), 0)
+    dUg = torch.zeros_like(Ug) if dU is not None else None
+    dIg = torch.zeros_like(Ig) if dI is not None else None
+    arn = (ar + B).contiguous()
+    _lib.check(lib.mmrec_bpr_bwd_f32(_p(Ug), _p(Ig), _p(Ig), _p(ar), _p(ar), _p(arn), B, d, _p(coef), _p(g), scale, _p(dUg),
+                                     _p(dIg), _p(dIg), _stream()), "bpr_bwd")
+    if dU is not None:
+        scatter_add_rows(users, dUg, dU)
+    if dI is not None:
+        scatter_add_rows(torch.cat((pos, neg)), dIg, dI)
+
+
 class _BprLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, U, I, users, pos, neg, variant, scale):
@@ -440,6 +482,9 @@ class _BprLoss(torch.autograd.Function):
         g = g.contiguous().to(torch.float32)
         dU = torch.zeros_like(U) if ctx.needs_input_grad[0] else None
         dI = torch.zeros_like(I) if ctx.needs_input_grad[1] else None
+        if DETERMINISTIC:
+            _bpr_bwd_deterministic(U, I, users, pos, neg, coef, g, ctx.scale, dU, dI)
+            return dU, dI, None, None, None, None, None
         _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg),
                                          users.numel(), U.shape[1], _p(coef), _p(g), ctx.scale, _p(dU),
                                          _p(dI), _p(dI), _stream()), "bpr_bwd")
@@ -501,8 +546,11 @@ class _BprLossShared(torch.autograd.Function):
                 continue
             dI = (own if own is not None else torch.zeros_like(I)) if need_i else None
             g = gs[t].contiguous().to(torch.float32)
-            _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), users.numel(), U.shape[1],
-                                             _p(coefs[t]), _p(g), ctx.scale, _p(dU), _p(dI), _p(dI), _stream()), "bpr_bwd")
+            if DETERMINISTIC:       # terms in order, each scattered without atomics: the shared dU gets them one after the other
+                _bpr_bwd_deterministic(U, I, users, pos, neg, coefs[t], g, ctx.scale, dU, dI)
+            else:
+                _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), users.numel(), U.shape[1],
+                                                 _p(coefs[t]), _p(g), ctx.scale, _p(dU), _p(dI), _p(dI), _stream()), "bpr_bwd")
             out.extend((dI, None, None))
         return (dU, None, None, None, None, None) + tuple(out)
 
@@ -549,6 +597,18 @@ class _InfoNCE(torch.autograd.Function):
         g = g.contiguous().to(torch.float32)
         dE1 = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
         dE2 = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        if DETERMINISTIC:      # per-sample rows (identity ids: one write each), then the position-ordered scatter
+            B = ids.numel()
+            ar = torch.arange(B, device=g.device)
+            r1 = torch.zeros(B, EMB_DIM, dtype=torch.float32, device=g.device) if dE1 is not None else None
+            r2 = torch.zeros(B, EMB_DIM, dtype=torch.float32, device=g.device) if dE2 is not None else None
+            _lib.check(lib.mmrec_infonce_bwd_f32(_p(ar), B, EMB_DIM, ctx.tau, _p(g), _p(r1), _p(r2), _p(ws), _stream()),
+                       "infonce_bwd")
+            if dE1 is not None:
+                scatter_add_rows(ids, r1, dE1)
+            if dE2 is not None:
+                scatter_add_rows(ids, r2, dE2)
+            return dE1, dE2, None, None
         _lib.check(lib.mmrec_infonce_bwd_f32(_p(ids), ids.numel(), EMB_DIM, ctx.tau, _p(g), _p(dE1),
                                              _p(dE2), _p(ws), _stream()), "infonce_bwd")
         return dE1, dE2, None, None
@@ -579,6 +639,8 @@ class _GatherSqNorm(torch.autograd.Function):
         E, ids = ctx.saved_tensors
         coef = (2.0 * g).contiguous().to(torch.float32)
         dE = torch.zeros_like(E)
+        if DETERMINISTIC:
+            return scatter_add_rows(ids, E.index_select(0, ids) * coef, dE), None
         _lib.check(lib.mmrec_gather_scale_add_bwd_f32(_p(E), _p(ids), ids.numel(), E.shape[1], _p(coef),
                                                       _p(dE), _stream()), "gather_scale_add_bwd")
         return dE, None
@@ -621,6 +683,13 @@ class _CosineMean(torch.autograd.Function):
         iy = idx.pop(0) if ctx.has[1] else None
         dX = torch.zeros_like(X)
         g = g.contiguous().to(torch.float32)
+        if DETERMINISTIC and ix is not None:      # gathered operands, one gradient row per sample, position-ordered scatter
+            Xg = X.index_select(0, ix)
+            Yg = Y.index_select(0, iy) if iy is not None else Y
+            rows = torch.zeros_like(Xg)
+            _lib.check(lib.mmrec_cosine_bwd_f32(_p(Xg), None, _p(Yg), None, ctx.B, X.shape[1], _p(coef), _p(g),
+                                                1.0 / max(ctx.B, 1), _p(rows), _stream()), "cosine_bwd")
+            return scatter_add_rows(ix, rows, dX), None, None, None
         _lib.check(lib.mmrec_cosine_bwd_f32(_p(X), _p(ix), _p(Y), _p(iy), ctx.B, X.shape[1], _p(coef), _p(g),
                                             1.0 / max(ctx.B, 1), _p(dX), _stream()), "cosine_bwd")
         return dX, None, None, None

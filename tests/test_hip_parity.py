@@ -391,6 +391,34 @@ def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden)
     l[1].backward()                                                      # only the second term is used
 
 
+@pytest.mark.parametrize("d", [64, 384])
+def test_scatter_add_rows_sorted_is_deterministic_and_exact(ops, dev, d):
+    """mmrec_scatter_add_rows_sorted_f32 (`hip_deterministic`): out[ids[b]] += rows[b] with duplicates summed in POSITION
+    order by one owner -- equals the sequential fp32 loop of the reference's CPU scatter bit for bit, skips ids < 0, adds to
+    what `out` holds; one id repeated 3000 times, ids that occur once, an empty batch."""
+    rng = np.random.default_rng(d)
+    n, n_rows = 5000, 400
+    ids = rng.integers(0, n_rows, n)
+    ids[:3000] = 7
+    rng.shuffle(ids)
+    ids[[5, 77]] = -1
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    base = rng.standard_normal((n_rows, d)).astype(np.float32)
+    ref = np.zeros((n_rows, d), dtype=np.float32)
+    for b in range(n):                                   # position order, fp32, like index_add on the CPU
+        if ids[b] >= 0:
+            ref[ids[b]] += rows[b]
+    ref = base + ref
+    out = D(base.copy(), dev)
+    ops.scatter_add_rows(D(ids.astype(np.int64), dev), D(rows, dev), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    out2 = D(base.copy(), dev)
+    ops.scatter_add_rows(D(ids.astype(np.int64), dev), D(rows, dev), out2)
+    assert torch.equal(out, out2)
+    ops.scatter_add_rows(torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, d, device=dev), out2)
+    assert torch.equal(out, out2)
+
+
 def test_bpr_extreme_scores(ops, dev):
     """logsigmoid / log(1e-10+sigmoid) differ for x << 0: both exact."""
     U = torch.zeros(4, 64)

@@ -210,6 +210,52 @@ def test_trainer_fit_runs_and_learns(tmp_path, golden, name, extra):
     assert 0.0 <= valid["recall@20"] <= 1.0 and score == max(score, 0)
 
 
+@pytest.mark.parametrize("name,extra", [("FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3}), ("LayerGCN", {"n_layers": 4, "dropout": 0.1}),
+                                        ("BM3", {"n_layers": 1, "dropout": 0.3, "reg_weight": 0.1}), ("MGCN", {"cl_loss": 0.01})])
+def test_hip_deterministic_runs_are_bitwise_repeatable(tmp_path, golden, name, extra):
+    """config `hip_deterministic`: the gradient scatters of the fused loss kernels (BPR / gather-norm / cosine / InfoNCE: hardware
+    fp32 atomics by default, order-dependent in the last ulp when an id occurs several times in a batch -- every batch of the
+    200-user golden dataset) sum duplicates in position order (mmrec_scatter_add_rows_sorted_f32), so two runs of
+    Trainer.fit from the same seed end with IDENTICAL parameters, bit for bit, like the reference's CPU path
+     -- eager and replayed as a hipGraph.  And the deterministic gradients are the atomic ones to rounding."""
+    if not USE_GPU:
+        pytest.skip("the CPU stand-ins are deterministic by construction")
+    from mmrec_amd import hip_ops
+    from mmrec_amd.common.trainer import Trainer
+    finals = []
+    try:
+        for run in range(2):
+            cfg = dict(extra, epochs=2, learning_rate=0.01, hip_deterministic=True)
+            config, train_data, valid_data, model = build(tmp_path / ("run%d" % run), golden, name, cfg)
+            for k, v in cfg.items():
+                config[k] = v
+            trainer = Trainer(config, model)
+            assert hip_ops.DETERMINISTIC
+            trainer.fit(train_data, valid_data=valid_data, test_data=valid_data, verbose=False)
+            finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+        # one step: deterministic gradients == the atomic ones up to the summation order
+        config, train_data, _, model = build(tmp_path / "grad", golden, name, dict(extra))
+        model.pre_epoch_processing()
+        batch = next(iter(train_data))
+        grads = []
+        for det in (True, False):
+            hip_ops.set_deterministic(det)
+            model.zero_grad()
+            if name == "BM3":
+                torch.manual_seed(5)                  # the same dropout masks in both passes
+            loss = model.calculate_loss(batch)
+            (sum(loss) if isinstance(loss, tuple) else loss).backward()
+            grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        for n in grads[0]:
+            scale = float(grads[1][n].abs().max())
+            assert float((grads[0][n] - grads[1][n]).abs().max()) <= 1e-5 * scale + 1e-12, n
+    finally:
+        hip_ops.set_deterministic(False)
+        torch.use_deterministic_algorithms(False)
+
+
 def test_freedom_lazy_feature_adam_equals_dense(tmp_path, golden):
     """FREEDOM with `lazy_feature_adam`: four optimizer steps (different batches) give the parameters of the dense
     fused Adam once the postponed row updates are flushed (to fp32 rounding: items that occur three or more times in
