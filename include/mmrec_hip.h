@@ -167,12 +167,17 @@ int mmrec_infonce_bwd_f32(const int64_t* ids, int32_t batch, int32_t d, float ta
  * F must be a multiple of 4; out features must be 64 (mmrec_linear_bwd_w_f32 also takes out = 64 j:
  * dY [n, out], dW [out, F], db [out]).  `workspace` (split-K partials) size from
  * mmrec_linear_workspace_bytes.  Deterministic (partials are summed in order).
+ * `tickets` of the forward (ABI 7; may be NULL): ceil(n / 128) int32 counters, ZERO before the first call and left at zero by
+ * every call: calls of at most MMREC_LINEAR_FUSED_REDUCE_MAX_ROWS rows then sum their split-K partials inside the launch (the
+ * last-arriving workgroup of a 128-row block, same order: same bits) instead of in a second launch.  One tickets buffer must
+ * not be used by two launches at the same time.
  * Wider layers (MMGCN's 4096 -> 256 MLP and 256 x 256 / 384 x 384 convolution weights, mmgcn.py:46-
  * 60,164-188): forward and dX are mmrec_gemm_nt_f32, dW / db the out = 64 j form above.
  * ---------------------------------------------------------------------------------------------- */
+#define MMREC_LINEAR_FUSED_REDUCE_MAX_ROWS 65536
 size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out);
 int mmrec_linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int32_t n,
-                         int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
+                         int32_t F, int32_t out, void* workspace, int32_t* tickets, mmrec_stream_t stream);
 int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW, float* db, int32_t n,
                            int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_x_f32(const float* dY, const float* W, float* dX, int32_t n, int32_t F,
@@ -200,7 +205,8 @@ int mmrec_gemm_nt_f32(const float* A, const float* B, const float* bias, float* 
  * ARGUMENT since ABI 5: the library reads no environment and keeps no state), the other shapes materialise
  * fp32-MFMA score blocks inside the workspace (topk.hip).  Unknown flag bits: MMREC_ERR_BAD_ARG.
  * ---------------------------------------------------------------------------------------------- */
-#define MMREC_TOPK_MAX 64
+#define MMREC_TOPK_MAX 128      /* kd = 64 with >= 4096 candidates (the fp16 filter path: every full-sort evaluation, e.g. topk: [10, 20, 50, 100]) */
+#define MMREC_TOPK_MAX_OTHER 64 /* every other shape (MMREC_ERR_UNSUPPORTED above it: callers fall back to their dense path) */
 #define MMREC_TOPK_NO_FILTER 1
 size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd, int32_t k);
 int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc, int32_t kd,

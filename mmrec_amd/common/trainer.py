@@ -262,7 +262,7 @@ class Trainer(AbstractTrainer):
         fused = self.fused_eval and hasattr(self.model, 'full_sort_topk')
         if fused:
             from mmrec_amd import hip_ops
-            fused = k <= hip_ops.TOPK_MAX        # torch.topk takes any k (e.g. topk: [10, 20, 50, 100]); the kernel 64
+            fused = k <= hip_ops.TOPK_MAX        # torch.topk takes any k; the kernels 128 (64 below 4096 items: the call says so)
         topk_batches = []
         for batch in eval_data:
             if fused:

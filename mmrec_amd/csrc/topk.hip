@@ -649,6 +649,7 @@ static int score_topk_impl(const float* Q, const float* C, const void* prepared,
     hipStream_t s = mmrec_stream(stream);
     if (p.materialise && !(flags & MMREC_TOPK_NO_FILTER) && topk64_filter_applicable(nq, nc, kd, k))
         return topk64_filter_launch(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
+    if (k > MMREC_TOPK_MAX_OTHER) return MMREC_ERR_UNSUPPORTED;   // 65..128: the fp16 filter path only (kd = 64, >= 4096 candidates)
     if (p.materialise) {
         float* Ct = nullptr;
         if (kd == 64) {

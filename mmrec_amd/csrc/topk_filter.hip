@@ -355,16 +355,30 @@ __global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
                 }
                 w[0] = ~w[0];
                 w[1] = ~w[1];
-            } else {   // bit = sign(thr' - score), thr' just below thr: score >= thr  <=>  score > thr'  <=>  sign bit set
+            } else {
+                // Large candidate sets: a query keeps ~65 of 500,000 candidates, so the 32 queries x 64 candidates a fragment
+                // scores in a stage hold a survivor in ~1 stage of 4.  The stage's largest score per lane (ONE v_max3 per two
+                // scores) decides, wave-uniformly, whether the 2-instruction-per-score bit extraction runs at all for the
+                // fragment: pass 2 was VALU co-bound at 8 VALU per MFMA (profiles/r03_topk_pmc.txt: MFMA pipe 53 % busy
+                // against 68 % in pass 1, whose per-score work is the max3 alone).
+                // bit = sign(thr' - score), thr' just below thr: score >= thr  <=>  score > thr'  <=>  sign bit set
+                float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(thr[0] - a0[r]), 31);
-                    w[1] = __builtin_amdgcn_alignbit(w[1], __float_as_uint(thr[1] - a1[r]), 31);
+                    mx0 = __builtin_fmaxf(__builtin_fmaxf(mx0, a0[r]), b0[r]);
+                    mx1 = __builtin_fmaxf(__builtin_fmaxf(mx1, a1[r]), b1[r]);
                 }
+                if (__ballot(mx0 > thr[0]) != 0ull) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(thr[0] - b0[r]), 31);
-                    w[1] = __builtin_amdgcn_alignbit(w[1], __float_as_uint(thr[1] - b1[r]), 31);
+                    for (int r = 0; r < 16; ++r) w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(thr[0] - a0[r]), 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(thr[0] - b0[r]), 31);
+                }
+                if (__ballot(mx1 > thr[1]) != 0ull) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) w[1] = __builtin_amdgcn_alignbit(w[1], __float_as_uint(thr[1] - a1[r]), 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) w[1] = __builtin_amdgcn_alignbit(w[1], __float_as_uint(thr[1] - b1[r]), 31);
                 }
             }
         }
@@ -507,6 +521,29 @@ __device__ __forceinline__ Cand sort_best64(const unsigned long long* list, int 
     return y0;
 }
 
+// Best 128 of list[0..n) (n >= 1) in rank order: y0 of lane l is the rank-l entry, y1 the rank-(64 + l) entry.  The best 128 of
+// (y0, y1, z) are y0 and the best 64 of (y1, z): an element of y0 has at most 63 + 64 = 127 entries ahead of it.
+__device__ __forceinline__ void sort_best128(const unsigned long long* list, int n, int lane, Cand& y0, Cand& y1) {
+    auto fetch = [&](int e) -> Cand { return e < n ? unpack_cand(list[e]) : Cand{-INFINITY, INT_MAX}; };
+    y0 = fetch(lane);
+    y1 = fetch(64 + lane);
+    bitonic128(y0, y1, lane);
+    for (int pos = 128; pos < n; pos += 64) {
+        Cand z = fetch(pos + lane);
+        bitonic128(y1, z, lane);     // y1 = best 64 of (y1, z), in rank order
+        bitonic128(y0, y1, lane);    // the 128 kept, in rank order again
+    }
+}
+// rank-ordered best min(k, 128) of a list: ranks 0..63 in y0, 64..127 in y1 (y1 untouched garbage-free when k <= 64)
+__device__ __forceinline__ void sort_best_k(const unsigned long long* list, int n, int lane, int k, Cand& y0, Cand& y1) {
+    if (k <= 64) {
+        y0 = sort_best64(list, n, lane);
+        y1 = Cand{-INFINITY, INT_MAX};
+    } else {
+        sort_best128(list, n, lane, y0, y1);
+    }
+}
+
 // Exact streaming top-k of ONE query by the F_SLOW_WAVES waves of a workgroup, for the queries the filter cannot
 // serve (heavy users whose k + m exceeds the number of groups, massive ties, fewer than k unmasked candidates): the
 // waves take the 64-candidate steps round robin, one candidate per lane, scores by the same tree as the fast path,
@@ -563,31 +600,43 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
             const unsigned long long b = __ballot(pass);
             if (pass) list[cnt + __popcll(b & lt)] = pack_cand(v, c);
             cnt += __popcll(b);
-            if (cnt <= F_CAPQ - 64) continue;
+            if (cnt <= F_CAPQ - 64) continue;      // (keeps <= 128 of the 256 slots after a compaction: room for >= 2 more steps)
         }
         // compaction (list nearly full) or this wave's final list: best min(cnt, k) entries, sorted
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const int n = cnt;
-        const Cand y = n > 0 ? sort_best64(list, n, lane) : Cand{-INFINITY, INT_MAX};
+        Cand y0 = Cand{-INFINITY, INT_MAX}, y1 = y0;
+        if (n > 0) sort_best_k(list, n, lane, k, y0, y1);
         const int keep = min(n, k);
         if (last) {
-            merged[wave * 64 + lane] = pack_cand(lane < keep ? y.v : -INFINITY, lane < keep ? y.i : INT_MAX);
+            merged[wave * 128 + lane] = pack_cand(lane < keep ? y0.v : -INFINITY, lane < keep ? y0.i : INT_MAX);
+            merged[wave * 128 + 64 + lane] = pack_cand(64 + lane < keep ? y1.v : -INFINITY, 64 + lane < keep ? y1.i : INT_MAX);
             break;
         }
-        if (lane < keep) list[lane] = pack_cand(y.v, y.i);
+        if (lane < keep) list[lane] = pack_cand(y0.v, y0.i);
+        if (64 + lane < keep) list[64 + lane] = pack_cand(y1.v, y1.i);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         cnt = keep;
-        if (n >= k) teff = fmaxf(teff, __shfl(y.v, k - 1, 64));
+        if (n >= k) teff = fmaxf(teff, k <= 64 ? __shfl(y0.v, k - 1, 64) : __shfl(y1.v, k - 65, 64));
     }
     __syncthreads();
     if (wave == 0) {
-        const Cand y = sort_best64(merged, F_SLOW_WAVES * 64, lane);
+        Cand y0, y1;
+        sort_best_k(merged, F_SLOW_WAVES * 128, lane, k, y0, y1);
         if (part) {
-            part[lane] = pack_cand(lane < k ? y.v : -INFINITY, lane < k ? y.i : INT_MAX);
-        } else if (lane < k) {
-            const bool ok = y.i != INT_MAX;
-            out_idx[(size_t)q * k + lane] = ok ? (int64_t)y.i : (int64_t)-1;
-            if (out_val) out_val[(size_t)q * k + lane] = ok ? y.v : -INFINITY;
+            part[lane] = pack_cand(lane < k ? y0.v : -INFINITY, lane < k ? y0.i : INT_MAX);
+            part[64 + lane] = pack_cand(64 + lane < k ? y1.v : -INFINITY, 64 + lane < k ? y1.i : INT_MAX);
+        } else {
+            if (lane < k) {
+                const bool ok = y0.i != INT_MAX;
+                out_idx[(size_t)q * k + lane] = ok ? (int64_t)y0.i : (int64_t)-1;
+                if (out_val) out_val[(size_t)q * k + lane] = ok ? y0.v : -INFINITY;
+            }
+            if (64 + lane < k) {
+                const bool ok = y1.i != INT_MAX;
+                out_idx[(size_t)q * k + 64 + lane] = ok ? (int64_t)y1.i : (int64_t)-1;
+                if (out_val) out_val[(size_t)q * k + 64 + lane] = ok ? y1.v : -INFINITY;
+            }
         }
     }
     __syncthreads();   // `merged` / the lists are reused by the workgroup's next query
@@ -700,10 +749,15 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             // D: sort, cut to k
-            const Cand y = sort_best64(s_l[wave], valid, lane);
+            Cand y0, y1;
+            sort_best_k(s_l[wave], valid, lane, k, y0, y1);
             if (lane < k) {
-                out_idx[(size_t)q * k + lane] = (int64_t)y.i;
-                if (out_val) out_val[(size_t)q * k + lane] = y.v;
+                out_idx[(size_t)q * k + lane] = (int64_t)y0.i;
+                if (out_val) out_val[(size_t)q * k + lane] = y0.v;
+            }
+            if (64 + lane < k) {
+                out_idx[(size_t)q * k + 64 + lane] = (int64_t)y1.i;
+                if (out_val) out_val[(size_t)q * k + 64 + lane] = y1.v;
             }
         }
     }
@@ -724,7 +778,7 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
     const int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val, int want_splits,
     unsigned long long* __restrict__ parts) {
     __shared__ unsigned long long s_l[F_SLOW_WAVES][F_CAPQ];
-    __shared__ unsigned long long s_m[F_SLOW_WAVES * 64];
+    __shared__ unsigned long long s_m[F_SLOW_WAVES * 128];
     __shared__ int32_t s_mask[F_SLOW_MASK_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nf = *n_flagged;
@@ -733,7 +787,7 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
         const int j = w / S, sp = w - j * S;
         const int st0 = (int)((long long)steps * sp / S), st1 = (int)((long long)steps * (sp + 1) / S);
         slow_topk(Q, C, nc, k, mask_rowptr, mask_col, flist[j], s_l, s_m, s_mask, lane, wave, out_idx, out_val, st0, st1,
-                  S > 1 ? parts + (size_t)w * 64 : nullptr);
+                  S > 1 ? parts + (size_t)w * 128 : nullptr);
     }
 }
 
@@ -746,12 +800,18 @@ __global__ __launch_bounds__(256) void filter_slow_merge_kernel(const int* __res
     const int S = slow_splits(nf, want_splits);
     if (S <= 1) return;
     for (int j = blockIdx.x * 4 + wave; j < nf; j += gridDim.x * 4) {
-        const Cand y = sort_best64(parts + (size_t)j * S * 64, S * 64, lane);
+        Cand y0, y1;
+        sort_best_k(parts + (size_t)j * S * 128, S * 128, lane, k, y0, y1);
         const int q = flist[j];
         if (lane < k) {
-            const bool ok = y.i != INT_MAX;
-            out_idx[(size_t)q * k + lane] = ok ? (int64_t)y.i : (int64_t)-1;
-            if (out_val) out_val[(size_t)q * k + lane] = ok ? y.v : -INFINITY;
+            const bool ok = y0.i != INT_MAX;
+            out_idx[(size_t)q * k + lane] = ok ? (int64_t)y0.i : (int64_t)-1;
+            if (out_val) out_val[(size_t)q * k + lane] = ok ? y0.v : -INFINITY;
+        }
+        if (64 + lane < k) {
+            const bool ok = y1.i != INT_MAX;
+            out_idx[(size_t)q * k + 64 + lane] = ok ? (int64_t)y1.i : (int64_t)-1;
+            if (out_val) out_val[(size_t)q * k + 64 + lane] = ok ? y1.v : -INFINITY;
         }
     }
 }
@@ -799,7 +859,7 @@ inline size_t al256f(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
-    return kd == 64 && k <= 64 && nc >= F_MIN_NC && nc <= 1000000 && nq >= 1;   // 16-bit ids inside a range
+    return kd == 64 && k <= 128 && nc >= F_MIN_NC && nc <= 1000000 && nq >= 1;
 }
 
 // The candidate side of a call -- column sums / max |c| (stats), the centred fp16 copy Cs and the largest centred row norm
@@ -826,7 +886,7 @@ size_t topk64_filter_workspace_bytes(int nq, int nc, int k) {
     const FilterPlan p = filter_plan(nq, nc);
     return al256f((size_t)p.nq_pad * 128) + topk64_filter_prepared_bytes(nc) + al256f((size_t)p.nq_pad * 4) + 256 +
            al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f(p.bits_bytes) +
-           al256f((size_t)F_SLOW_PARTS * 64 * 8);
+           al256f((size_t)F_SLOW_PARTS * 128 * 8);
 }
 
 int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,

@@ -68,6 +68,37 @@ def D(a, dev, grad=False):
     return t.requires_grad_() if grad else t
 
 
+def test_linear_fused_slab_sum_equals_two_launches(ops, dev, monkeypatch):
+    """mmrec_linear_fwd_f32 `tickets` (ABI 7): calls of <= 65,536 rows sum their split-K partials inside the launch (last-arriving
+    workgroup of a 128-row block, the reduce kernel's order) -- the same bits as the two-launch form, call after call (tickets
+    left at zero), for ragged n and both feature widths, and under hipGraph replay."""
+    rng = np.random.default_rng(4)
+    for n, F in ((1, 4096), (7050, 384), (129, 4096), (18357, 4096), (7050, 4096)):
+        X = D(np.maximum(rng.standard_normal((n, F)), 0).astype(np.float32), dev)
+        W = D((rng.standard_normal((64, F)) * 0.02).astype(np.float32), dev)
+        b = D(rng.standard_normal(64).astype(np.float32) * 0.01, dev)
+        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", False)
+        ref = ops.linear(X, W, b)
+        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", True)
+        for _ in range(3):
+            assert torch.equal(ops.linear(X, W, b), ref), (n, F)
+        assert int(ops._linear_tickets(n, dev).abs().sum()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.no_grad():
+            ops.linear(X, W, b)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, stream=side):
+                Yg = ops.linear(X, W, b)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        Yg.zero_()
+        cg.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Yg, ref)
+
+
 # ---------------------------------------------------------------------------------------- SpMM
 def _random_csr(rng, n_rows, n_cols, degs):
     rows = np.repeat(np.arange(n_rows), degs)
@@ -786,6 +817,33 @@ def test_topk_filter_word_lists(ops, dev, nq, nc):
     b = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert np.array_equal(a[0].cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("nq,nc,k", [(600, 7050, 100), (300, 40_037, 128), (64, 70_001, 65), (200, 4096, 100)])
+def test_topk_filter_k_up_to_128(ops, dev, nq, nc, k):
+    """k = 65..128 on the fp16 filter path (kd = 64, >= 4096 candidates; `topk: [10, 20, 50, 100]` evaluates fused instead
+    of through rocBLAS + torch.topk): rows of bits and word lists, the final kernel's two-register rank order, the slow queue
+    (a heavy user whose k + #masked exceeds the group maxima; a query whose candidates all tie; >= 65,536 candidates: split
+    over workgroups and merged) -- against orc.mask_topk (trainer.py:304-309); smaller candidate sets say UNSUPPORTED."""
+    from mmrec_amd._lib import MMRecHipError
+    rng = np.random.default_rng(nq + nc + k)
+    Q = rng.standard_normal((nq, 64)).astype(np.float32) * 0.2
+    C = (rng.standard_normal((nc, 64)) * 0.2 + 0.1).astype(np.float32)
+    C[100:100 + 300 * 7:7] = 0.5                       # 300 identical candidates ...
+    Q[5] = 1.0                                         # ... that are this query's best: ties broken by id, lists overflow
+    heavy = rng.choice(nc, 900, replace=False)         # k + m > 512 group maxima: slow queue
+    rows = np.concatenate([rng.integers(0, nq, 10 * nq), np.repeat(9, heavy.shape[0])])
+    cols = np.concatenate([rng.integers(0, nc, 10 * nq), heavy])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    idx = _topk_check(ops, dev, Q, C, k, mask)
+    masked5 = set(mask[1][mask[0] == 5].tolist())
+    assert idx[5].tolist() == [c for c in range(100, 100 + 300 * 7, 7) if c not in masked5][:k]
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    a = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
+    assert np.array_equal(a[0].cpu().numpy(), idx)                       # repeatable
+    with pytest.raises(MMRecHipError):
+        ops.score_topk(D(Q, dev), D(C[:3000], dev), k)                   # below 4096 candidates: 64 is the limit
 
 
 @pytest.mark.parametrize("nq,nc", [(700, 7050), (300, 40_037), (100, 3000)])

@@ -210,7 +210,7 @@ def test_trainer_fit_runs_and_learns(tmp_path, golden, name, extra):
     assert 0.0 <= valid["recall@20"] <= 1.0 and score == max(score, 0)
 
 
-@pytest.mark.parametrize("name,extra", [("FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3}), ("LayerGCN", {"n_layers": 4, "dropout": 0.1}),
+@pytest.mark.parametrize("name,extra", [("FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3}), ("LayerGCN", {"n_layers": 4, "dropout": 0.1, "reg_weight": 1e-3}),
                                         ("BM3", {"n_layers": 1, "dropout": 0.3, "reg_weight": 0.1}), ("MGCN", {"cl_loss": 0.01})])
 def test_hip_deterministic_runs_are_bitwise_repeatable(tmp_path, golden, name, extra):
     """config `hip_deterministic`: the gradient scatters of the fused loss kernels (BPR / gather-norm / cosine / InfoNCE: hardware

@@ -15,9 +15,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
-    "p1s1": ["-DMMREC_TF_P1S=1"],                 # pass 1 on every stage
-    "p1s2": ["-DMMREC_TF_P1S=2"],                 # ... on every 2nd stage (the default from 32,768 candidates on)
-    "p1s3": ["-DMMREC_TF_P1S=3"],
+    "current": [],                                # the tree as it is
+    "p1s2": ["-DMMREC_TF_P1S=2"],                 # pass 1 on every 2nd stage (i.i.d. embeddings like these cases': faster; see filter_plan)
 }
 
 
