@@ -60,7 +60,7 @@ const char* mmrec_error_string(int err);
  * long_tickets (ABI 7; may be NULL): n_long int32 counters, ZERO before the first call and left at zero by every call.
  * With them, graphs of at most MMREC_SPMM_FUSED_REDUCE_MAX_ROWS rows finish a multi-chunk row inside the launch (the chunk
  * block that arrives last sums the partials, in the same order: same bits) instead of in a second launch -- these graphs
- * are cache resident and latency bound (Amazon-Baby: 18.5 -> 14 us per layer).  One graph's tickets / partials must not be
+ * are cache resident and latency bound (Amazon-Baby: 18.5 -> 15.4 us per layer).  One graph's tickets / partials must not be
  * used by two launches at the same time.
  *
  * Epilogue per row r (y = alpha * sum + beta * Z[r], Z may be NULL):
@@ -167,17 +167,13 @@ int mmrec_infonce_bwd_f32(const int64_t* ids, int32_t batch, int32_t d, float ta
  * F must be a multiple of 4; out features must be 64 (mmrec_linear_bwd_w_f32 also takes out = 64 j:
  * dY [n, out], dW [out, F], db [out]).  `workspace` (split-K partials) size from
  * mmrec_linear_workspace_bytes.  Deterministic (partials are summed in order).
- * `tickets` of the forward (ABI 7; may be NULL): ceil(n / 128) int32 counters, ZERO before the first call and left at zero by
- * every call: calls of at most MMREC_LINEAR_FUSED_REDUCE_MAX_ROWS rows then sum their split-K partials inside the launch (the
- * last-arriving workgroup of a 128-row block, same order: same bits) instead of in a second launch.  One tickets buffer must
- * not be used by two launches at the same time.
+
  * Wider layers (MMGCN's 4096 -> 256 MLP and 256 x 256 / 384 x 384 convolution weights, mmgcn.py:46-
  * 60,164-188): forward and dX are mmrec_gemm_nt_f32, dW / db the out = 64 j form above.
  * ---------------------------------------------------------------------------------------------- */
-#define MMREC_LINEAR_FUSED_REDUCE_MAX_ROWS 65536
 size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out);
 int mmrec_linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int32_t n,
-                         int32_t F, int32_t out, void* workspace, int32_t* tickets, mmrec_stream_t stream);
+                         int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW, float* db, int32_t n,
                            int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_x_f32(const float* dY, const float* W, float* dX, int32_t n, int32_t F,

@@ -43,7 +43,7 @@ SIGNATURES = {
     "mmrec_infonce_fwd_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P, _P]),
     "mmrec_infonce_bwd_f32": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P, _P, _P, _P]),
     "mmrec_linear_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
-    "mmrec_linear_fwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "mmrec_linear_fwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "mmrec_linear_bwd_w_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "mmrec_linear_bwd_x_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "mmrec_gemm_nt_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),

@@ -107,35 +107,6 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
-// float4 `i4` of sum_s part[s] (+ bias), slab order with four independent chains (a single chain of up to 64 dependent adds
-// was latency bound: 17 us for a few MB); ONE order for the reduce kernel and the fused last-arriver sum.  COHERENT: the
-// slabs were written by other workgroups of the same launch (agent-scope loads).
-template <bool COHERENT>
-__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ part, int nslab, size_t slab_elems, size_t i4,
-                                            const float* __restrict__ bias) {
-    auto ld = [&](int s) -> float4 {
-        const float4* p = reinterpret_cast<const float4*>(part + (size_t)s * slab_elems) + i4;
-        if (!COHERENT) return *p;
-        unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float4*>(p));
-        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
-                           __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
-    };
-    float4 t0 = f4_zero(), t1 = f4_zero(), t2 = f4_zero(), t3 = f4_zero();
-    int s = 0;
-    for (; s + 3 < nslab; s += 4) {
-        t0 = f4_add(t0, ld(s));
-        t1 = f4_add(t1, ld(s + 1));
-        t2 = f4_add(t2, ld(s + 2));
-        t3 = f4_add(t3, ld(s + 3));
-    }
-    for (; s < nslab; ++s) t0 = f4_add(t0, ld(s));
-    float4 t = f4_add(f4_add(t0, t1), f4_add(t2, t3));
-    if (bias) t = f4_add(t, reinterpret_cast<const float4*>(bias)[i4 & 15]);
-    return t;
-}
-
 // ------------------------------------------------------------------- forward, LDS-DMA pipeline
 // Same tile (128 x 64 per workgroup, wave w owns rows 32w..+31) but the operands go HBM -> LDS with
 // `buffer_load_dwordx4 ... lds` (no staging VGPRs, no address VALU: scalar k offset + per-lane
@@ -151,8 +122,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_kernel(const float* __r
                                                                 const float* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 float* __restrict__ out, int n, int F,
-                                                                int k_chunk, int32_t* __restrict__ tickets,
-                                                                float* __restrict__ Y) {
+                                                                int k_chunk) {
     __shared__ __attribute__((aligned(1024))) float Xs0[LIN_BM * DM_BK], Xs1[LIN_BM * DM_BK], Xs2[LIN_BM * DM_BK];
     __shared__ __attribute__((aligned(1024))) float Ws0[64 * DM_BK], Ws1[64 * DM_BK], Ws2[64 * DM_BK];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -225,39 +195,14 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_kernel(const float* __r
     float* dst = out + (size_t)blockIdx.y * n * 64;
     const float b0 = (bias && gridDim.y == 1) ? bias[i] : 0.f;
     const float b1 = (bias && gridDim.y == 1) ? bias[32 + i] : 0.f;
-    const bool fused = tickets != nullptr && gridDim.y > 1;    // split K with the slab sum done by the last workgroup of this row block
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wave * 32 + d_row(r, lane);
         if (row < n) {
-            if (fused) {   // read by another workgroup of this launch: agent-scope stores (no L2 write-back fence needed)
-                __hip_atomic_store(dst + (size_t)row * 64 + i, acc0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + (size_t)row * 64 + 32 + i, acc1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                dst[(size_t)row * 64 + i] = acc0[r] + b0;
-                dst[(size_t)row * 64 + 32 + i] = acc1[r] + b1;
-            }
+            dst[(size_t)row * 64 + i] = acc0[r] + b0;
+            dst[(size_t)row * 64 + 32 + i] = acc1[r] + b1;
         }
     }
-    if (!fused) return;
-    // Last arriver of the row block sums the K slabs in the order of slab_reduce_kernel (same bits as the two-launch form:
-    // 4.8 us of a 43 us Amazon-Baby projection were that second launch) and leaves the ticket at zero for the next call.
-    __shared__ int s_last;
-    __builtin_amdgcn_s_waitcnt(0);                 // my slab rows are out
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();                               // ... and every wave's
-    if (tid == 0)
-        s_last = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const size_t slab = (size_t)n * 64;
-    const int rows = min(LIN_BM, n - m0);
-    for (int e = tid; e < rows * 16; e += 256) {   // float4 e of the block's [rows, 64] outputs
-        const size_t i4 = (size_t)m0 * 16 + e;
-        reinterpret_cast<float4*>(Y)[i4] = slab_sum4<true>(out, (int)gridDim.y, slab, i4, bias);
-    }
-    if (tid == 0) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[idx] = sum_s part[s][idx] (+ bias[idx % 64]) in slab order; total = n*64 (multiple of 4).
@@ -267,7 +212,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           float* __restrict__ out) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_elems) return;
-    reinterpret_cast<float4*>(out)[i4] = slab_sum4<false>(part, nslab, slab_elems, i4, bias);
+    // four independent chains keep the slab loads in flight (a single chain of up to 64 dependent
+    // adds was latency bound: 17 us for a few MB); the combination order is still fixed
+    float4 t0 = f4_zero(), t1 = f4_zero(), t2 = f4_zero(), t3 = f4_zero();
+    int s = 0;
+    for (; s + 3 < nslab; s += 4) {
+        t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)(s + 0) * slab_elems)[i4]);
+        t1 = f4_add(t1, reinterpret_cast<const float4*>(part + (size_t)(s + 1) * slab_elems)[i4]);
+        t2 = f4_add(t2, reinterpret_cast<const float4*>(part + (size_t)(s + 2) * slab_elems)[i4]);
+        t3 = f4_add(t3, reinterpret_cast<const float4*>(part + (size_t)(s + 3) * slab_elems)[i4]);
+    }
+    for (; s < nslab; ++s) t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)s * slab_elems)[i4]);
+    float4 t = f4_add(f4_add(t0, t1), f4_add(t2, t3));
+    if (bias) t = f4_add(t, reinterpret_cast<const float4*>(bias)[i4 & 15]);
+    reinterpret_cast<float4*>(out)[i4] = t;
 }
 
 // ------------------------------------------------------------------------------------- backward W
@@ -522,7 +480,7 @@ extern "C" size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out
 }
 
 extern "C" int mmrec_linear_fwd_f32(const float* X, const float* W, const float* b, float* Y,
-                                    int32_t n, int32_t F, int32_t out, void* workspace, int32_t* tickets,
+                                    int32_t n, int32_t F, int32_t out, void* workspace,
                                     mmrec_stream_t stream) {
     if (out != 64 || F <= 0 || (F & 3)) return MMREC_ERR_UNSUPPORTED;
     if (n < 0) return MMREC_ERR_BAD_ARG;
@@ -540,19 +498,14 @@ extern "C" int mmrec_linear_fwd_f32(const float* X, const float* W, const float*
     const dim3 grid(ceil_div(n, LIN_BM), nsplit);
     // X larger than the 256 MB Infinity Cache is read once per call: stream it non-temporal
     const bool nt = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);
-    // `tickets` (ceil(n / 128) zeroed int32, left at zero): the K slabs of a row block are summed by its last-arriving
-    // workgroup inside the launch -- for the small, latency-bound calls only (a second launch is nothing next to 2 ms)
-    const bool fuse = tickets && dma && nsplit > 1 && n <= MMREC_LINEAR_FUSED_REDUCE_MAX_ROWS;
     if (dma && nt)
-        hipLaunchKernelGGL(linear_fwd_dma_kernel<true>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk,
-                           fuse ? tickets : (int32_t*)nullptr, Y);
+        hipLaunchKernelGGL(linear_fwd_dma_kernel<true>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk);
     else if (dma)
-        hipLaunchKernelGGL(linear_fwd_dma_kernel<false>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk,
-                           fuse ? tickets : (int32_t*)nullptr, Y);
+        hipLaunchKernelGGL(linear_fwd_dma_kernel<false>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk);
     else
         hipLaunchKernelGGL(linear_fwd_kernel<MMREC_GEMM_PROBE_MODE>, grid, dim3(256),
                            MMREC_GEMM_DYN_LDS, s, X, W, b, dst, n, F, chunk);
-    if (nsplit > 1 && !fuse) {
+    if (nsplit > 1) {
         float* part = dst;
         const size_t elems = (size_t)n * 64;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0,

@@ -705,23 +705,6 @@ def cosine_mean(X, ix, Y, iy):
 # ------------------------------------------------------------------------------------------------
 # P3  modal projection
 # ------------------------------------------------------------------------------------------------
-_LINEAR_TICKETS = {}
-LINEAR_FUSED_REDUCE = True     # False: the split-K partials are summed by a second launch (A/B measurements, parity tests)
-
-
-def _linear_tickets(n, device):
-    """zeroed last-arriver counters of the forward projection's 128-row blocks (mmrec_linear_fwd_f32 `tickets`): one
-    buffer per device, left at zero by every call; projections run one after the other on the stream they are enqueued on"""
-    if not LINEAR_FUSED_REDUCE:
-        return None
-    need = -(-n // 128)
-    key = str(device)
-    t = _LINEAR_TICKETS.get(key)
-    if t is None or t.numel() < need:
-        t = _LINEAR_TICKETS[key] = torch.zeros(max(need, 1024), dtype=torch.int32, device=device)
-    return t
-
-
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, b):
@@ -735,8 +718,8 @@ class _Linear(torch.autograd.Function):
             b = _chk(b.contiguous(), torch.float32, "b", 1)
         Y = torch.empty(n, 64, dtype=torch.float32, device=X.device)
         ws = _ws(lib.mmrec_linear_workspace_bytes(n, F, 64), X.device)
-        _lib.check(lib.mmrec_linear_fwd_f32(_p(X), _p(W), _p(b), _p(Y), n, F, 64, _p(ws), _p(_linear_tickets(n, X.device)),
-                                            _stream()), "linear_fwd")
+        _lib.check(lib.mmrec_linear_fwd_f32(_p(X), _p(W), _p(b), _p(Y), n, F, 64, _p(ws), _stream()),
+                   "linear_fwd")
         ctx.save_for_backward(X, W)
         ctx.has_b = b is not None
         return Y

@@ -68,37 +68,6 @@ def D(a, dev, grad=False):
     return t.requires_grad_() if grad else t
 
 
-def test_linear_fused_slab_sum_equals_two_launches(ops, dev, monkeypatch):
-    """mmrec_linear_fwd_f32 `tickets` (ABI 7): calls of <= 65,536 rows sum their split-K partials inside the launch (last-arriving
-    workgroup of a 128-row block, the reduce kernel's order) -- the same bits as the two-launch form, call after call (tickets
-    left at zero), for ragged n and both feature widths, and under hipGraph replay."""
-    rng = np.random.default_rng(4)
-    for n, F in ((1, 4096), (7050, 384), (129, 4096), (18357, 4096), (7050, 4096)):
-        X = D(np.maximum(rng.standard_normal((n, F)), 0).astype(np.float32), dev)
-        W = D((rng.standard_normal((64, F)) * 0.02).astype(np.float32), dev)
-        b = D(rng.standard_normal(64).astype(np.float32) * 0.01, dev)
-        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", False)
-        ref = ops.linear(X, W, b)
-        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", True)
-        for _ in range(3):
-            assert torch.equal(ops.linear(X, W, b), ref), (n, F)
-        assert int(ops._linear_tickets(n, dev).abs().sum()) == 0
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        with torch.no_grad():
-            ops.linear(X, W, b)
-            cg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cg, stream=side):
-                Yg = ops.linear(X, W, b)
-    torch.cuda.current_stream().wait_stream(side)
-    for _ in range(3):
-        Yg.zero_()
-        cg.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(Yg, ref)
-
-
 # ---------------------------------------------------------------------------------------- SpMM
 def _random_csr(rng, n_rows, n_cols, degs):
     rows = np.repeat(np.arange(n_rows), degs)

@@ -80,7 +80,7 @@ def test_argument_errors_without_gpu(lib):
                                   256, None, None, 0, 0, None, None, None) == 10002   # d != 64
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 65, None, None, None, 0, None) == 10001
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 5, None, None, None, 2, None) == 10001   # unknown flag
-    assert lib.mmrec_linear_fwd_f32(None, None, None, None, 4, 6, 64, None, None, None) == 10002  # F % 4
+    assert lib.mmrec_linear_fwd_f32(None, None, None, None, 4, 6, 64, None, None) == 10002  # F % 4
 
 
 def test_topk_workspace_covers_both_kd64_paths(lib):

@@ -13,11 +13,11 @@ int main(int argc, char** argv) {
     hipMalloc(&ws, mmrec_linear_workspace_bytes(n, F, 64));
     hipMemset(X, 0x3c, (size_t)n * F * 4); hipMemset(W, 0x3c, 64 * F * 4); hipMemset(b, 0, 256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) mmrec_linear_fwd_f32(X, W, b, Y, n, F, 64, ws, nullptr, nullptr);
+    for (int i = 0; i < 3; ++i) mmrec_linear_fwd_f32(X, W, b, Y, n, F, 64, ws, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
     const int reps = 20;
-    for (int i = 0; i < reps; ++i) mmrec_linear_fwd_f32(X, W, b, Y, n, F, 64, ws, nullptr, nullptr);
+    for (int i = 0; i < reps; ++i) mmrec_linear_fwd_f32(X, W, b, Y, n, F, 64, ws, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("n %d ablation mask %2d : %.1f us / call (incl. split-K reduce)  %.1f TF\n", n, MMREC_GEMM_PROBE_MODE, ms / reps * 1e3, 2.0 * n * F * 64 / (ms / reps * 1e-3) / 1e12);
