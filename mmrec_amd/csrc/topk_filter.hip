@@ -223,8 +223,11 @@ struct PassArgs {
 //          again.  Instead a lane appends its NON-ZERO words to the query's list (one atomic slot counter per query;
 //          ~1 % of the words).  The append is software-pipelined: the atomic of one flush is consumed at the next, so no
 //          wave waits a memory round trip in the stage loop.  List order is arbitrary; the final kernel sorts anyway.
+#ifndef MMREC_TF_OCC3      // probe: three workgroups per CU for the word-list pass 2 (168 VGPRs: 12 spilled)
+#define MMREC_TF_OCC3 0
+#endif
 template <bool FILTER, bool SPARSE = false>
-__global__ __launch_bounds__(256, 2) void filter_pass_kernel(const PassArgs a) {
+__global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) void filter_pass_kernel(const PassArgs a) {
     __shared__ uint4 s_c[2][2][256];   // [buffer][tile of the stage][row * 8 + swizzled chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;

@@ -1159,6 +1159,58 @@ def test_lazy_row_adam_under_graph_replay_equals_dense(dev):
     assert not torch.equal(a[0].cpu(), w0)
 
 
+def test_lazy_row_adam_long_id_lists_under_capture(dev):
+    """Round-2 advice: a step with more ids than the step kernel's LDS position list holds (n > MMREC_ADAM_ROWS_MAX_IDS =
+    16,000, i.e. train_batch_size > 8,000) pre-sums the row gradients into the owner slots on the host side of the call; that
+    pre-sum used boolean-mask indexing (`x[mask]` = nonzero() = a host synchronisation: illegal inside a hipGraph capture, a
+    stall in eager mode).  It is sync-free now (rows of id -1 add zeros): the step is CAPTURED and replayed, with -1 slots in
+    the list, and equals the dense table under the same optimizer (dyadic coefficients: bit for bit)."""
+    from mmrec_amd.common.graph_step import GraphedTrainStep
+    from mmrec_amd.common.lazy_rows import MAX_IDS, LazyRowEmbedding
+    from mmrec_amd.common.optim import HipAdam
+    n, F, B = 3000, 64, MAX_IDS + 1500
+    g = torch.Generator().manual_seed(12)
+    w0 = torch.randn(n, F, generator=g)
+    coefs = (torch.randint(-8, 9, (n, F), generator=g).float() / 8).to(dev)
+    batches = []
+    for b in range(6):
+        ids = torch.randint(0, n, (1, B), generator=g)
+        ids[0, torch.randperm(B, generator=g)[:200]] = -1              # slots of rows another rank would own
+        batches.append(ids)
+
+    class Net(torch.nn.Module):
+        def __init__(self, lazy):
+            super().__init__()
+            cls = LazyRowEmbedding if lazy else torch.nn.Embedding
+            self.table = cls.from_pretrained(w0.clone(), freeze=False)
+            self.lazy = lazy
+            if lazy:
+                self.table.allow_missing = True
+
+        def calculate_loss(self, batch):
+            ids = batch[0]
+            present = (ids >= 0).unsqueeze(1).float()
+            safe = ids.clamp_min(0)
+            rows = self.table.rows(ids) if self.lazy else self.table.weight[safe] * present
+            return (rows * coefs[safe] * present).sum()
+
+    def run(lazy):
+        net = Net(lazy).to(dev)
+        opt = HipAdam(net.parameters(), lr=1e-2, capturable=True)
+        step = GraphedTrainStep(net, opt, steps_per_capture=len(batches) + 2)
+        for b in batches:
+            step(b.to(dev))
+        assert not step.failed and step.graph is not None, "the step with the long id list must be capturable"
+        if lazy:
+            net.table.flush()
+        torch.cuda.synchronize()
+        st = opt.state[net.table.weight]
+        return net.table.weight.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_lazy_row_adam_skips_missing_rows(dev):
     """item-sharded feature tables (ShardedFREEDOM): a batch slot whose item another rank owns is id -1 = "no row" -- a
     zero row forward, no gradient, no catch-up / step work; the present rows evolve exactly as under dense Adam."""

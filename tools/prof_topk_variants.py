@@ -4,7 +4,7 @@
     python tools/prof_topk_variants.py build      # here (no GPU): variant libraries into tools/probe_libs/
     python tools/prof_topk_variants.py run        # on the GPU: parity of every variant vs the materialised fp32 path + ms per call
 
-`base` = topk_filter.hip of the round-2 tree (git d349f5d).  Round 3 used this harness for the pass-1 stage stride
+Round 3 used this harness for the pass-1 stage stride
 (profiles/r03_topk_pass1_stride_ab.log) and for the one-workgroup-per-CU pass kernel that was built, measured and dropped
 (profiles/r03_topk_wide_kernel_ab.log; the kernel itself is in git history: commit "top-K filter: v_max3 group maxima ...")."""
 import os
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
     "current": [],                                # the tree as it is
-    "p1s2": ["-DMMREC_TF_P1S=2"],                 # pass 1 on every 2nd stage (i.i.d. embeddings like these cases': faster; see filter_plan)
+    "occ3": ["-DMMREC_TF_OCC3=1"],                # word-list pass 2 at three workgroups per CU (168 VGPRs, 12 spilled)
 }
 
 
@@ -28,21 +28,14 @@ def build():
     objs = [os.path.join(b.OBJ, s.replace(".hip", ".o")) for s in b.SOURCES if s != "topk_filter.hip"]
     extra = b.EXTRA_FLAGS.get("topk_filter.hip", [])
     jobs = [(name, os.path.join(b.CSRC, "topk_filter.hip"), defs + extra) for name, defs in VARIANTS.items()]
-    base_src = os.path.join(b.CSRC, "_topk_filter_r02.hip")
-    with open(base_src, "w") as f:
-        f.write(subprocess.run(["git", "-C", ROOT, "show", "d349f5d:mmrec_amd/csrc/topk_filter.hip"], capture_output=True,
-                               text=True, check=True).stdout)
-    jobs.append(("base", base_src, []))
-    try:
-        for name, src, defs in jobs:
-            o = os.path.join(OUT, "tfw_%s.o" % name)
-            subprocess.check_call([b._hipcc()] + b.FLAGS + defs + ["-c", src, "-o", o])
-            subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
-                                   os.path.join(OUT, "libmmrec_tfw_%s.so" % name)] + objs + [o])
-            os.remove(o)
-            print("built", name, flush=True)
-    finally:
-        os.remove(base_src)
+    # (the round-2 source no longer links against the current topk.hip: ABI 7 added entry points it does not define)
+    for name, src, defs in jobs:
+        o = os.path.join(OUT, "tfw_%s.o" % name)
+        subprocess.check_call([b._hipcc()] + b.FLAGS + defs + ["-c", src, "-o", o])
+        subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                               os.path.join(OUT, "libmmrec_tfw_%s.so" % name)] + objs + [o])
+        os.remove(o)
+        print("built", name, flush=True)
 
 
 def cases(dev):
@@ -108,7 +101,7 @@ def run_one():
 
 
 def run():
-    names = ["base"] + list(VARIANTS)
+    names = list(VARIANTS)
     for rnd in range(2):
         for name in names:
             env = dict(os.environ, MMREC_HIP_LIB=os.path.join(OUT, "libmmrec_tfw_%s.so" % name))
