@@ -195,13 +195,13 @@ int mmrec_gemm_nt_f32(const float* A, const float* B, const float* bias, float* 
  * Output sorted by score descending (ties: lower candidate id first): out_idx[nq,k] int64,
  * out_val[nq,k] fp32 (may be NULL).  Masked candidates score -1e10 like the reference, so they can
  * only appear when fewer than k candidates are unmasked.  workspace: mmrec_topk_workspace_bytes.
- * Scores are fp32 dot products in every implementation behind this entry point: kd == 64 with >= 4096 candidates
+ * Scores are fp32 dot products in every implementation behind this entry point: kd == 64 or 128 with >= 4096 candidates
  * runs an fp16 matrix-core FILTER with a proven error bound and rescores the ~k survivors per query exactly
  * (topk_filter.hip; `flags & MMREC_TOPK_NO_FILTER` keeps the materialised fp32 path for A/B measurements -- an
  * ARGUMENT since ABI 5: the library reads no environment and keeps no state), the other shapes materialise
  * fp32-MFMA score blocks inside the workspace (topk.hip).  Unknown flag bits: MMREC_ERR_BAD_ARG.
  * ---------------------------------------------------------------------------------------------- */
-#define MMREC_TOPK_MAX 128      /* kd = 64 with >= 4096 candidates (the fp16 filter path: every full-sort evaluation, e.g. topk: [10, 20, 50, 100]) */
+#define MMREC_TOPK_MAX 128      /* kd = 64 or 128 with >= 4096 candidates (the fp16 filter path: every full-sort evaluation, e.g. topk: [10, 20, 50, 100]) */
 #define MMREC_TOPK_MAX_OTHER 64 /* every other shape (MMREC_ERR_UNSUPPORTED above it: callers fall back to their dense path) */
 #define MMREC_TOPK_NO_FILTER 1
 size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd, int32_t k);

@@ -612,7 +612,7 @@ extern "C" size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd,
         const size_t b = (kd == 64 ? al256((size_t)kd_pad * ldc * 4) : 0) + al256((size_t)p.qb_rows * ldc * 4) +
                          al256((size_t)p.qb_rows * GEMM64_MAX_GROUPS * 4);
         // either path may serve the call (`flags` of mmrec_score_topk_f32 decides): size for both
-        const size_t f = topk64_filter_applicable(nq, nc, kd, k) ? topk64_filter_workspace_bytes(nq, nc, k) : 0;
+        const size_t f = topk64_filter_applicable(nq, nc, kd, k) ? topk64_filter_workspace_bytes(nq, nc, kd, k) : 0;
         return b > f ? b : f;
     }
     size_t b = al256((size_t)kd_pad * ldc * 4);               // Ct
@@ -624,13 +624,13 @@ extern "C" size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd,
 
 extern "C" size_t mmrec_topk_prepared_bytes(int32_t nc, int32_t kd) {
     // the fp16 filter's candidate side; 0 = no shape of this (nc, kd) is served by it
-    return (nc > 0 && topk64_filter_applicable(1, nc, kd, 1)) ? topk64_filter_prepared_bytes(nc) : 0;
+    return (nc > 0 && topk64_filter_applicable(1, nc, kd, 1)) ? topk64_filter_prepared_bytes(nc, kd) : 0;
 }
 
 extern "C" int mmrec_topk_prepare_f32(const float* C, int32_t nc, int32_t kd, void* prepared, mmrec_stream_t stream) {
     if (!C || !prepared || nc <= 0) return MMREC_ERR_BAD_ARG;
     if (!topk64_filter_applicable(1, nc, kd, 1)) return MMREC_ERR_UNSUPPORTED;
-    return topk64_filter_prepare(C, nc, prepared, mmrec_stream(stream));
+    return topk64_filter_prepare(C, nc, kd, prepared, mmrec_stream(stream));
 }
 
 static int score_topk_impl(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
@@ -648,7 +648,7 @@ static int score_topk_impl(const float* Q, const float* C, const void* prepared,
     char* ws = static_cast<char*>(workspace);
     hipStream_t s = mmrec_stream(stream);
     if (p.materialise && !(flags & MMREC_TOPK_NO_FILTER) && topk64_filter_applicable(nq, nc, kd, k))
-        return topk64_filter_launch(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
+        return topk64_filter_launch(Q, C, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
     if (k > MMREC_TOPK_MAX_OTHER) return MMREC_ERR_UNSUPPORTED;   // 65..128: the fp16 filter path only (kd = 64, >= 4096 candidates)
     if (p.materialise) {
         float* Ct = nullptr;

@@ -80,42 +80,50 @@ __device__ __forceinline__ unsigned f2key(float f) {   // monotone: a < b  <=>  
 __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
-// stats[0..63] = column sums of C, stats[65] = key(max |c_ij|) (queries are scaled row by row: nothing global to
-// collect for them).  Grid: the 128-row slabs of C.
-__global__ __launch_bounds__(256) void filter_stats_kernel(const float* __restrict__ C, int nc, float* __restrict__ stats) {
+// The candidate statistics block (1 KiB at the head of the prepared buffer): stats[0 .. kd) = column sums of C, the two
+// monotone keys at fixed word offsets: ST_CMAX = key(max |c_ij|), ST_NMAX = key(max norm of a converted, centred row).
+// (Queries are scaled row by row: nothing global to collect for them.)  kd = 64 or 128 floats per row.
+constexpr int ST_WORDS = 256, ST_CMAX = 252, ST_NMAX = 253;
+// Grid: the 128-row slabs of C.
+__global__ __launch_bounds__(256) void filter_stats_kernel(const float* __restrict__ C, int nc, int kd4, float* __restrict__ stats) {
     __shared__ float4 s_sum[16][16];
     __shared__ float s_mx[4];
     const float* X = C;
     const int n = nc, r0 = blockIdx.x * 128;
     const int sub = threadIdx.x & 15, rr = threadIdx.x >> 4;
-    float4 v[8];   // the thread's 8 rows, all loads in flight at once
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = r0 + rr + 16 * j;
-        v[j] = r < n ? reinterpret_cast<const float4*>(X)[(size_t)r * 16 + sub] : f4_zero();
-    }
-    float4 sum = f4_zero();
     float mx = 0.f;
+    for (int cc = sub; cc < kd4; cc += 16) {      // 16 float4 columns per sweep (one for kd = 64, two for 128)
+        float4 v[8];   // the thread's 8 rows, all loads in flight at once
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sum = f4_add(sum, v[j]);
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + rr + 16 * j;
+            v[j] = r < n ? reinterpret_cast<const float4*>(X)[(size_t)r * kd4 + cc] : f4_zero();
+        }
+        float4 sum = f4_zero();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sum = f4_add(sum, v[j]);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+        }
+        __syncthreads();                           // (s_sum of the previous sweep has been read)
+        s_sum[rr][sub] = sum;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float4 t = f4_zero();
+            for (int j = 0; j < 16; ++j) t = f4_add(t, s_sum[j][threadIdx.x]);
+            const int c0 = 4 * (cc - sub + threadIdx.x);
+            atomicAdd(stats + c0 + 0, t.x);
+            atomicAdd(stats + c0 + 1, t.y);
+            atomicAdd(stats + c0 + 2, t.z);
+            atomicAdd(stats + c0 + 3, t.w);
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
-    s_sum[rr][sub] = sum;
     __syncthreads();
     if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(stats) + 65, f2key(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
-    if (threadIdx.x < 16) {
-        float4 t = f4_zero();
-        for (int j = 0; j < 16; ++j) t = f4_add(t, s_sum[j][threadIdx.x]);
-        atomicAdd(stats + 4 * threadIdx.x + 0, t.x);
-        atomicAdd(stats + 4 * threadIdx.x + 1, t.y);
-        atomicAdd(stats + 4 * threadIdx.x + 2, t.z);
-        atomicAdd(stats + 4 * threadIdx.x + 3, t.w);
-    }
+        atomicMax(reinterpret_cast<unsigned*>(stats) + ST_CMAX, f2key(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
 }
 
 // power of two that brings values of magnitude <= mx (mx > 0) below 2^13: products of two such numbers summed
@@ -127,15 +135,18 @@ __device__ __forceinline__ float fp16_scale(float mx) {
     return ldexpf(1.f, min(13 - ex, 120));   // denormal-sized inputs: the scale itself must stay finite
 }
 
-// X [n][64] fp32 -> Xs [n_pad][8] uint4 = fp16(scale * (x - centre)), 8 halves per chunk, natural k order; rows >= n
-// are zero.  CAND: centre = column mean and *maxnorm_key = max row norm of the converted rows; else norm[row].
-template <bool CAND>
+// X [n][kd] fp32 -> fp16(scale * (x - centre)), 8 halves per 16-B chunk, natural k order; rows >= n are zero.  W = kd / 8
+// threads per row (8 or 16 consecutive lanes).  Queries: Xs[row][W chunks].  CAND: centre = column mean, *maxnorm_key = max
+// row norm of the converted rows, and the TILE layout the pass kernels stage: 64-candidate stage t, 64-column block kb ->
+// tile t * KB + kb = 64 rows x 8 chunks contiguous (8 KB), so a pass walks kd = 128 as twice as many 64-wide tiles.
+template <bool CAND, int W>
 __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __restrict__ X, int n, int n_pad,
                                                             const float* __restrict__ stats, uint4* __restrict__ Xs,
                                                             float* __restrict__ norm, unsigned* __restrict__ maxnorm_key,
                                                             int* __restrict__ zero_one, int* __restrict__ zero_rows) {
+    constexpr int KB = W / 8;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int row = t >> 3, ch = t & 7;   // grid covers n_pad rows exactly (n_pad % 32 == 0)
+    const int row = t / W, ch = t % W;   // grid covers n_pad rows exactly (n_pad % 64 == 0)
     if (!CAND) {   // the call's counters, zeroed on the way (one int, and one int per real row)
         if (t == 0 && zero_one) *zero_one = 0;
         if (ch == 0 && row < n && zero_rows) zero_rows[row] = 0;
@@ -144,8 +155,8 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = 0.f;
     if (row < n) {
-        const float4 a = reinterpret_cast<const float4*>(X)[(size_t)row * 16 + ch * 2];
-        const float4 b = reinterpret_cast<const float4*>(X)[(size_t)row * 16 + ch * 2 + 1];
+        const float4 a = reinterpret_cast<const float4*>(X)[(size_t)row * (2 * W) + ch * 2];
+        const float4 b = reinterpret_cast<const float4*>(X)[(size_t)row * (2 * W) + ch * 2 + 1];
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
         if (CAND) {
             const float inv = 1.f / (float)n;
@@ -155,14 +166,13 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
     }
     float scale;
     if (CAND) {   // one scale for all candidates: |c - mean| <= 2 max|c|
-        scale = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[65]));
-    } else {      // a query row's own scale (the 8 threads of a row are 8 consecutive lanes)
+        scale = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
+    } else {      // a query row's own scale (the W threads of a row are W consecutive lanes)
         float mx = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(x[j]));
-        mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 8));
+#pragma unroll
+        for (int o = W / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, W));
         scale = fp16_scale(mx);
     }
     unsigned hb[8];
@@ -174,19 +184,18 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
         const float back = (float)hv;
         ss = fmaf(back, back, ss);
     }
-    Xs[(size_t)row * 8 + ch] = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16),
-                                          hb[6] | (hb[7] << 16));
-    ss += __shfl_xor(ss, 4, 8);
-    ss += __shfl_xor(ss, 2, 8);
-    ss += __shfl_xor(ss, 1, 8);
+    const size_t dst = CAND ? (((size_t)(row >> 6) * KB + (ch >> 3)) * 64 + (row & 63)) * 8 + (ch & 7) : (size_t)row * W + ch;
+    Xs[dst] = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+#pragma unroll
+    for (int o = W / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, W);
     // norms of the ROUNDED rows, inflated by the rounding (1 + 2^-11) and by sqrt's own error
     const float nrm = sqrtf(ss) * 1.0005f;
     if (!CAND && ch == 0) norm[row] = nrm;
-    if (CAND) {   // one atomic per workgroup (n_pad * 8 is a multiple of 256: no partial workgroups)
+    if (CAND) {   // one atomic per workgroup (n_pad * W is a multiple of 256: no partial workgroups)
         __shared__ float s_mx[4];
         float mx = nrm;
 #pragma unroll
-        for (int o = 32; o >= 8; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        for (int o = 32; o >= W; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
         __syncthreads();
         if (threadIdx.x == 0)
@@ -226,9 +235,11 @@ struct PassArgs {
 #ifndef MMREC_TF_OCC3      // probe: three workgroups per CU for the word-list pass 2 (168 VGPRs: 12 spilled)
 #define MMREC_TF_OCC3 0
 #endif
-template <bool FILTER, bool SPARSE = false>
+// KB = kd / 64 (1 or 2): a row of 128 columns is walked as two 64-wide tiles per 64-candidate stage (the conversion lays the
+// candidates out tile by tile), accumulating into the same accumulators; the per-score work runs once per stage.
+template <bool FILTER, bool SPARSE, int KB>
 __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) void filter_pass_kernel(const PassArgs a) {
-    __shared__ uint4 s_c[2][2][256];   // [buffer][tile of the stage][row * 8 + swizzled chunk]
+    __shared__ uint4 s_c[2][2][256];   // [buffer][32-row half of the tile][row * 8 + swizzled chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * F_QWG + wave * 64;
@@ -241,18 +252,19 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     // Its loop then runs over virtual stages t0 + j that stand for the real stages t0 + j * S.
     const int S = FILTER ? 1 : a.p1_stride;
     const int t1 = FILTER ? t1r : t0 + (max(t1r - t0, 0) + S - 1) / S;
+    const int u0 = t0 * KB, u1 = t1 * KB;          // the same in 64 x 64 TILES (micro-steps of the pipeline below)
     float gm[2][16];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gm[f][r] = -INFINITY;
     if (t0 < t1) {   // uniform
-    // query fragments: lane (i, h) holds B[k = 32 h + 8 s + j][n = i], i.e. chunk 4 h + s of its query row
-    half8 qf[2][4];
+    // query fragments: lane (i, h) holds B[k = 32 h + 8 s + j][n = i], i.e. chunk 4 h + s of column block kb of its query row
+    half8 qf[2][4 * KB];
     // C operand of a chain's first MFMA: 0 (pass 1) / -thr of the lane's query (pass 2: acc = score - thr, the pass / fail
-    // bit is the accumulator's sign).  The word-list variant has no 32 registers to spare for it (256 per wave at two
-    // workgroups per CU): it keeps thr in one register per fragment and subtracts per score.
-    constexpr bool CINIT = FILTER && !SPARSE;
+    // bit is the accumulator's sign).  The word-list variant and the 128-wide rows have no 32 registers to spare for it (256
+    // per wave at two workgroups per CU): they keep thr in one register per fragment and subtract per score.
+    constexpr bool CINIT = FILTER && !SPARSE && KB == 1;
     acc16 cinit[2];
     float thr[2];
     unsigned long long* brow[2];
@@ -260,7 +272,8 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     for (int f = 0; f < 2; ++f) {
         const int q = q0 + f * 32 + i;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[f][s] = __builtin_bit_cast(half8, a.Qs[(size_t)q * 8 + h * 4 + s]);
+        for (int c = 0; c < 4 * KB; ++c)
+            qf[f][c] = __builtin_bit_cast(half8, a.Qs[(size_t)q * (8 * KB) + (c >> 2) * 8 + h * 4 + (c & 3)]);
         const float nt = CINIT ? ((q < a.nq) ? -a.thr[q] : -INFINITY) : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[f][r] = nt;
@@ -281,33 +294,37 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
             ps[f] = -1;
         }
     };
-    // stage fill: thread -> (row rr, chunk cc) of both tiles
+    // tile fill: thread -> (row rr, chunk cc) of both 32-row halves
     const int rr = tid >> 3, cc = tid & 7;
     const int slot = rr * 8 + (cc ^ ((rr >> 1) & 7));
     const int sw = (i >> 1) & 7;
-    // global -> register ring, F_PF stages ahead (the L2 / HBM latency is several stage times), -> LDS double
+    // global -> register ring, F_PF tiles ahead (the L2 / HBM latency is several tile times), -> LDS double
     // buffer.  The ring is eight named registers, not an array: an indexed private array went to scratch.
     uint4 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;
     ra0 = rb0 = ra1 = rb1 = ra2 = rb2 = ra3 = rb3 = make_uint4(0, 0, 0, 0);
-    auto gload = [&](int t, uint4& xa, uint4& xb) __attribute__((always_inline)) {
-        const size_t o = ((size_t)(t0 + (t - t0) * S) * 64 + rr) * 8 + cc;
+    auto gload = [&](int u, uint4& xa, uint4& xb) __attribute__((always_inline)) {     // micro-step u -> its tile
+        const int tv = u / KB, kb = u - tv * KB;
+        const size_t o = (((size_t)(t0 + (tv - t0) * S) * KB + kb) * 64 + rr) * 8 + cc;
         xa = a.Cs[o];
         xb = a.Cs[o + 32 * 8];
     };
-    gload(t0, ra0, rb0);
-    if (t0 + 1 < t1) gload(t0 + 1, ra1, rb1);
-    if (t0 + 2 < t1) gload(t0 + 2, ra2, rb2);
-    if (t0 + 3 < t1) gload(t0 + 3, ra3, rb3);
+    gload(u0, ra0, rb0);
+    if (u0 + 1 < u1) gload(u0 + 1, ra1, rb1);
+    if (u0 + 2 < u1) gload(u0 + 2, ra2, rb2);
+    if (u0 + 3 < u1) gload(u0 + 3, ra3, rb3);
     s_c[0][0][slot] = ra0;
     s_c[0][1][slot] = rb0;
     __syncthreads();
     int cur = 0;
     unsigned w[2] = {0u, 0u};   // pass 2: pass / fail bits of the current stage, per fragment
     unsigned long long bw[2] = {0ull, 0ull};
-    // one stage t; (fa, fb) = ring slot that held it (free now: refilled with stage t + F_PF), (na, nb) = slot of stage t + 1
-    auto step = [&](int t, uint4& fa, uint4& fb, const uint4& na, const uint4& nb) __attribute__((always_inline)) {
-        if (t < t1) {         // uniform
-        if (t + F_PF < t1 && !(MMREC_TF_PROBE & 4)) gload(t + F_PF, fa, fb);
+    acc16 a0 = cinit[0], a1 = cinit[1], b0 = cinit[0], b1 = cinit[1];   // a: rows 0..31 of the stage, b: 32..63; 0 / 1: query fragment
+    // one micro-step u at position POS of the unrolled sequence (column block kb = POS % KB: a range starts at an even u);
+    // (fa, fb) = ring slot that held its tile (free now: refilled with u + F_PF), (na, nb) = slot of u + 1
+    auto step = [&](int u, auto POS, uint4& fa, uint4& fb, const uint4& na, const uint4& nb) __attribute__((always_inline)) {
+        constexpr int kb = decltype(POS)::value % KB;
+        if (u < u1) {         // uniform
+        if (u + F_PF < u1 && !(MMREC_TF_PROBE & 4)) gload(u + F_PF, fa, fb);
         half8 ca[4], cb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -315,25 +332,27 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
             ca[s] = __builtin_bit_cast(half8, s_c[cur][0][i * 8 + ((h * 4 + s) ^ sw)]);
             cb[s] = __builtin_bit_cast(half8, s_c[cur][1][i * 8 + ((h * 4 + s) ^ sw)]);
         }
-        acc16 a0 = cinit[0], a1 = cinit[1], b0 = cinit[0], b1 = cinit[1];   // a: tile 0, b: tile 1; 0 / 1: query fragment
+        if (kb == 0) { a0 = cinit[0]; a1 = cinit[1]; b0 = cinit[0]; b1 = cinit[1]; }    // a new stage
         if (MMREC_TF_PROBE & 1) {
             a0[0] = __builtin_bit_cast(float4, ca[0]).x; a1[5] = __builtin_bit_cast(float4, cb[3]).y;
             b0[9] = __builtin_bit_cast(float4, ca[2]).z; b1[2] = __builtin_bit_cast(float4, cb[1]).w;
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca[s], qf[0][s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca[s], qf[1][s], a1, 0, 0, 0);
-                b0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb[s], qf[0][s], b0, 0, 0, 0);
-                b1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb[s], qf[1][s], b1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca[s], qf[0][kb * 4 + s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca[s], qf[1][kb * 4 + s], a1, 0, 0, 0);
+                b0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb[s], qf[0][kb * 4 + s], b0, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb[s], qf[1][kb * 4 + s], b1, 0, 0, 0);
             }
         }
-        if (t + 1 < t1) {   // the next stage goes to the other LDS buffer while the matrix pipe drains
+        if (u + 1 < u1) {   // the next tile goes to the other LDS buffer while the matrix pipe drains
             s_c[cur ^ 1][0][slot] = na;
             s_c[cur ^ 1][1][slot] = nb;
         }
         // a?[r] / b?[r] = score of candidate 64 t (+ 32) + (r & 3) + 8 (r >> 2) + 4 h for query q0 + 32 f + i
-        if (MMREC_TF_PROBE & 8) {
+        if (kb != KB - 1) {
+            // (more column blocks of this stage to come)
+        } else if (MMREC_TF_PROBE & 8) {
             if (a0[3] == 1234.5f) gm[0][0] = a1[7] + b0[1] + b1[2];
         } else if (!FILTER) {
 #pragma unroll
@@ -387,10 +406,10 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
         }
         if (!(MMREC_TF_PROBE & 16)) __syncthreads();
         cur ^= 1;
-        } else if (FILTER) {
+        } else if (FILTER && kb == KB - 1) {
             w[0] = w[1] = 0u;
         }
-        if (FILTER) {
+        if (FILTER && kb == KB - 1) {      // a stage done: its 32 bits per fragment
             bw[0] = (bw[0] << 32) | w[0];
             bw[1] = (bw[1] << 32) | w[1];
         }
@@ -411,15 +430,19 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
                 }
         }
     };
-    for (int tb = t0; tb < t1; tb += F_PF) {
-        step(tb, ra0, rb0, ra1, rb1);
-        step(tb + 1, ra1, rb1, ra2, rb2);
-        flush((tb - t_r0) >> 1);
-        step(tb + 2, ra2, rb2, ra3, rb3);
-        step(tb + 3, ra3, rb3, ra0, rb0);
-        flush(((tb - t_r0) >> 1) + 1);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    using P3 = std::integral_constant<int, 3>;
+    for (int ub = u0; ub < u1; ub += F_PF) {       // four micro-steps = four stages (KB = 1) / two stages (KB = 2)
+        step(ub, P0{}, ra0, rb0, ra1, rb1);
+        step(ub + 1, P1{}, ra1, rb1, ra2, rb2);
+        if (KB == 1) flush((ub - u0) >> 1);
+        step(ub + 2, P2{}, ra2, rb2, ra3, rb3);
+        step(ub + 3, P3{}, ra3, rb3, ra0, rb0);
+        flush(KB == 1 ? ((ub - u0) >> 1) + 1 : (ub - u0) >> 2);
     }
-    static_assert(F_PF == 4, "the step sequence above is written for a 4-slot ring");
+    static_assert(F_PF == 4 && (KB == 1 || KB == 2), "the step sequence above is written for a 4-slot ring and 1 or 2 column blocks");
     if (FILTER && SPARSE) commit();
     }
     if (!FILTER) {
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
                                                            int nc, int k, const int32_t* __restrict__ mask_rowptr,
                                                            const float* __restrict__ qnorm,
                                                            const unsigned* __restrict__ cmax_key,
-                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ stats, int kd,
                                                            float* __restrict__ thr, int* __restrict__ flag) {
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -487,15 +510,21 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
     // eps in the scaled (by the query's own and the candidates' power of two), centred units of the approximate
     // scores: fp16 rounding of both operands (2u + u^2 and
     // the accumulation, 1.0e-3 of |q| max|c'|) plus the fp32 rounding of the EXACT scores the final kernel ranks by
-    // (64 * 2^-24 of |q| max|c|, the uncentred norm: |c| <= |c'| + |mean|)
-    float mu = lane < 64 ? stats[lane] / (float)nc : 0.f;
-    mu = wave_sum(mu * mu);
+    // (kd * 2^-24 of |q| max|c|, the uncentred norm: |c| <= |c'| + |mean|)
+    float mu = 0.f;
+    for (int c = lane; c < kd; c += 64) {
+        const float mc = stats[c] / (float)nc;
+        mu = fmaf(mc, mc, mu);
+    }
+    mu = wave_sum(mu);
     if (lane == 0) {
-        const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[65]));
+        const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
         const float cmax = key2f(*cmax_key);
-        // + 2^-22 (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
-        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * (cmax + sc * sqrtf(mu))) +
-                          2.4e-7f * (qnorm[q] + cmax);
+        const float kb = (float)kd * (1.f / 64.f);
+        // + 2^-25 sqrt(kd) (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
+        // (sum |x_i| <= sqrt(kd) |x|; 2.4e-7 = 2^-22 for kd = 64)
+        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax + sc * sqrtf(mu))) +
+                          2.4e-7f * sqrtf(kb) * (qnorm[q] + cmax);
         thr[q] = key2f(cur) - 2.f * eps;
         flag[q] = 0;
     }
@@ -509,6 +538,18 @@ __device__ __forceinline__ float tree16(const float (&p)[16]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) l2[j] = l1[j] + l1[j + 4];
     return (l2[0] + l2[2]) + (l2[1] + l2[3]);
+}
+
+// kd = 128: chunk products j and j + 16 are added first (what a lane of the final kernel holds), then the same tree
+template <int KB>
+__device__ __forceinline__ float exact_score(const float4* __restrict__ q4, const float4* __restrict__ c4) {
+    float p[16];
+#pragma unroll
+    for (int ch = 0; ch < 16; ++ch) {
+        p[ch] = f4_dot(q4[ch], c4[ch]);
+        if (KB == 2) p[ch] += f4_dot(q4[ch + 16], c4[ch + 16]);
+    }
+    return tree16(p);
 }
 
 // Sort list[0..n) (n >= 1): on return y0 of lane l is the rank-l entry (l < 64).
@@ -558,6 +599,7 @@ __device__ __forceinline__ void sort_best_k(const unsigned long long* list, int 
 // (64 packed entries) instead of the outputs -- large candidate sets are split over several workgroups per query and
 // merged by filter_slow_merge_kernel (one workgroup streaming 500K candidates for ONE flagged query took 5 ms, as long
 // as the whole 20,000-query block of the fast path).
+template <int KB>
 __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
                                           const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
                                           int q, unsigned long long (*lists)[F_CAPQ], unsigned long long* merged,
@@ -568,7 +610,7 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int steps = st1;
     q = __builtin_amdgcn_readfirstlane(q);
-    const float4* q4 = reinterpret_cast<const float4*>(Q) + (size_t)q * 16;   // wave-uniform: scalar loads
+    const float4* q4 = reinterpret_cast<const float4*>(Q) + (size_t)q * (16 * KB);   // wave-uniform: scalar loads
     // the query's sorted mask list: binary-searched per candidate, from LDS when it fits (heavy users are what this
     // path is for: a per-lane cursor over a list in global memory made them cost ~0.1 ms each)
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0;
@@ -587,11 +629,7 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
             const int c = it * 64 + lane;
             float v = -INFINITY;
             if (c < nc) {
-                const float4* c4 = reinterpret_cast<const float4*>(C) + (size_t)c * 16;
-                float p[16];
-#pragma unroll
-                for (int ch = 0; ch < 16; ++ch) p[ch] = f4_dot(q4[ch], c4[ch]);
-                v = tree16(p);
+                v = exact_score<KB>(q4, reinterpret_cast<const float4*>(C) + (size_t)c * (16 * KB));
                 int lo = 0, hi = m;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
@@ -645,7 +683,7 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     __syncthreads();   // `merged` / the lists are reused by the workgroup's next query
 }
 
-template <bool SPARSE>
+template <bool SPARSE, int KB>
 __global__ __launch_bounds__(256) void filter_final_kernel(
     const float* __restrict__ Q, const float* __restrict__ C, int nq, int nc, int k,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
@@ -681,7 +719,9 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
         return live ? row[e] : 0ull;
     };
     unsigned long long x_next = word(lane, wi_next);
-    const float4 qv = reinterpret_cast<const float4*>(Q)[(size_t)q * 16 + (lane & 15)];
+    float4 qv[KB];      // the lane's chunks (lane & 15) + 16 kb of the query row
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) qv[kb] = reinterpret_cast<const float4*>(Q)[(size_t)q * (16 * KB) + kb * 16 + (lane & 15)];
     const int fl = flag[q];
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
     bool bad = fl != 0 || m > F_MASK_LDS || n_app > F_WCAP;
@@ -738,15 +778,19 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             const int sub = lane & 15, g = lane >> 4;
             for (int e0 = 0; e0 < valid; e0 += 32) {
                 int id[8];
-                float4 cv[8];
+                float4 cv[8][KB];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) id[u] = e0 + 4 * u + g < valid ? s_ids[wave][e0 + 4 * u + g] : -1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    cv[u] = id[u] >= 0 ? reinterpret_cast<const float4*>(C)[(size_t)id[u] * 16 + sub] : f4_zero();
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+                        cv[u][kb] = id[u] >= 0 ? reinterpret_cast<const float4*>(C)[(size_t)id[u] * (16 * KB) + kb * 16 + sub] : f4_zero();
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const float sc = row16_sum(f4_dot(qv, cv[u]));
+                    float part = f4_dot(qv[0], cv[u][0]);
+                    if (KB == 2) part += f4_dot(qv[KB - 1], cv[u][KB - 1]);      // chunk + 16: the order of exact_score<2>
+                    const float sc = row16_sum(part);
                     if (sub == 0 && id[u] >= 0) s_l[wave][e0 + 4 * u + g] = pack_cand(sc, id[u]);
                 }
             }
@@ -775,6 +819,7 @@ __device__ __forceinline__ int slow_splits(int nf, int want) {
     return nf > 0 ? max(1, min(want, F_SLOW_PARTS / nf)) : 1;
 }
 
+template <int KB>
 __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
     const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col, const int* __restrict__ flist,
@@ -789,7 +834,7 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
     for (int w = blockIdx.x; w < nf * S; w += gridDim.x) {   // uniform per workgroup
         const int j = w / S, sp = w - j * S;
         const int st0 = (int)((long long)steps * sp / S), st1 = (int)((long long)steps * (sp + 1) / S);
-        slow_topk(Q, C, nc, k, mask_rowptr, mask_col, flist[j], s_l, s_m, s_mask, lane, wave, out_idx, out_val, st0, st1,
+        slow_topk<KB>(Q, C, nc, k, mask_rowptr, mask_col, flist[j], s_l, s_m, s_mask, lane, wave, out_idx, out_val, st0, st1,
                   S > 1 ? parts + (size_t)w * 128 : nullptr);
     }
 }
@@ -862,43 +907,51 @@ inline size_t al256f(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
-    return kd == 64 && k <= 128 && nc >= F_MIN_NC && nc <= 1000000 && nq >= 1;
+    return (kd == 64 || kd == 128) && k <= 128 && nc >= F_MIN_NC && nc <= 1000000 && nq >= 1;
 }
 
 // The candidate side of a call -- column sums / max |c| (stats), the centred fp16 copy Cs and the largest centred row norm
 // -- depends on C only.  A caller that ranks several query blocks against the SAME table (the batches of one evaluation and
-// its valid / test pair, trainer.py:298-310: weights are frozen) prepares it once (`prepared`: 512 B of statistics + Cs) and
+// its valid / test pair, trainer.py:298-310: weights are frozen) prepares it once (`prepared`: 1 KiB of statistics + Cs) and
 // hands it to every call; without it a call prepares its own copy inside its workspace.
-size_t topk64_filter_prepared_bytes(int nc) {
-    return 512 + al256f((size_t)cdiv_i(nc, 64) * 64 * 128);
+size_t topk64_filter_prepared_bytes(int nc, int kd) {
+    return ST_WORDS * 4 + al256f((size_t)cdiv_i(nc, 64) * 64 * 2 * kd);
 }
 
-int topk64_filter_prepare(const float* C, int nc, void* prepared, hipStream_t s) {
+int topk64_filter_prepare(const float* C, int nc, int kd, void* prepared, hipStream_t s) {
     const int n_stages = cdiv_i(nc, 64);
-    float* stats = static_cast<float*>(prepared);          // [0..63] column sums of C, [65] max |c| key, [66] max |c'| key
-    uint4* Cs = reinterpret_cast<uint4*>(static_cast<char*>(prepared) + 512);
-    hipError_t e = hipMemsetAsync(stats, 0, 512, s);
+    float* stats = static_cast<float*>(prepared);
+    uint4* Cs = reinterpret_cast<uint4*>(static_cast<char*>(prepared) + ST_WORDS * 4);
+    unsigned* nmax = reinterpret_cast<unsigned*>(stats) + ST_NMAX;
+    hipError_t e = hipMemsetAsync(stats, 0, ST_WORDS * 4, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, stats);
-    hipLaunchKernelGGL((filter_convert_kernel<true>), dim3(n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc, n_stages * 64,
-                       stats, Cs, (float*)nullptr, reinterpret_cast<unsigned*>(stats) + 66, (int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, kd / 4, stats);
+    if (kd == 64)
+        hipLaunchKernelGGL((filter_convert_kernel<true, 8>), dim3(n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc, n_stages * 64,
+                           stats, Cs, (float*)nullptr, nmax, (int*)nullptr, (int*)nullptr);
+    else
+        hipLaunchKernelGGL((filter_convert_kernel<true, 16>), dim3(n_stages * 64 * 16 / 256), dim3(256), 0, s, C, nc, n_stages * 64,
+                           stats, Cs, (float*)nullptr, nmax, (int*)nullptr, (int*)nullptr);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
-size_t topk64_filter_workspace_bytes(int nq, int nc, int k) {
+size_t topk64_filter_workspace_bytes(int nq, int nc, int kd, int k) {
     const FilterPlan p = filter_plan(nq, nc);
-    return al256f((size_t)p.nq_pad * 128) + topk64_filter_prepared_bytes(nc) + al256f((size_t)p.nq_pad * 4) + 256 +
+    return al256f((size_t)p.nq_pad * 2 * kd) + topk64_filter_prepared_bytes(nc, kd) + al256f((size_t)p.nq_pad * 4) + 256 +
            al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f(p.bits_bytes) +
            al256f((size_t)F_SLOW_PARTS * 128 * 8);
 }
 
-int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,
-                         const int32_t* mask_col, int k, int64_t* out_idx, float* out_val, void* workspace,
-                         const void* prepared, hipStream_t s) {
+namespace {
+template <int KB>
+int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,
+                     const int32_t* mask_col, int k, int64_t* out_idx, float* out_val, void* workspace,
+                     const void* prepared, hipStream_t s) {
+    constexpr int kd = 64 * KB;
     const FilterPlan p = filter_plan(nq, nc);
     char* ws = static_cast<char*>(workspace);
-    uint4* Qs = reinterpret_cast<uint4*>(ws);          ws += al256f((size_t)p.nq_pad * 128);
-    char* own = ws;                                    ws += topk64_filter_prepared_bytes(nc);   // used when `prepared` is null
+    uint4* Qs = reinterpret_cast<uint4*>(ws);          ws += al256f((size_t)p.nq_pad * 2 * kd);
+    char* own = ws;                                    ws += topk64_filter_prepared_bytes(nc, kd);   // used when `prepared` is null
     float* qnorm = reinterpret_cast<float*>(ws);       ws += al256f((size_t)p.nq_pad * 4);
     int* n_flagged = reinterpret_cast<int*>(ws);       ws += 256;                                // length of the slow queue
     unsigned* gkeys = reinterpret_cast<unsigned*>(ws); ws += al256f((size_t)nq * p.n_groups * 4);
@@ -909,39 +962,47 @@ int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, const i
     int* wcnt = reinterpret_cast<int*>(ws);                                 // sparse: [nq] counters, then
     uint4* wlist = reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4));   //         [nq][F_WCAP] entries
     ws += al256f(p.bits_bytes);
-    unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][64]
+    unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][128]
     if (!prepared) {
-        const int rc = topk64_filter_prepare(C, nc, own, s);
+        const int rc = topk64_filter_prepare(C, nc, kd, own, s);
         if (rc != 0) return rc;
         prepared = own;
     }
     const float* stats = static_cast<const float*>(prepared);
-    const unsigned* cmax = reinterpret_cast<const unsigned*>(prepared) + 66;
-    const uint4* Cs = reinterpret_cast<const uint4*>(static_cast<const char*>(prepared) + 512);
+    const unsigned* cmax = reinterpret_cast<const unsigned*>(prepared) + ST_NMAX;
+    const uint4* Cs = reinterpret_cast<const uint4*>(static_cast<const char*>(prepared) + ST_WORDS * 4);
     // the query-side conversion also zeroes the call's counters (slow-queue length, word-list lengths): no memset launches
-    hipLaunchKernelGGL((filter_convert_kernel<false>), dim3(p.nq_pad * 8 / 256), dim3(256), 0, s, Q, nq, p.nq_pad, stats,
-                       Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
+    hipLaunchKernelGGL((filter_convert_kernel<false, 8 * KB>), dim3(p.nq_pad * 8 * KB / 256), dim3(256), 0, s, Q, nq, p.nq_pad,
+                       stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
     PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, gkeys, thr, bits, wcnt, wlist};
     const dim3 grid(p.qblocks, p.R);
-    hipLaunchKernelGGL((filter_pass_kernel<false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
-                       mask_rowptr, qnorm, cmax, stats, thr, flag);
+                       mask_rowptr, qnorm, cmax, stats, kd, thr, flag);
     if (p.sparse)
-        hipLaunchKernelGGL((filter_pass_kernel<true, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_pass_kernel<true, true, KB>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((filter_pass_kernel<true, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_pass_kernel<true, false, KB>), grid, dim3(256), 0, s, a);
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
     if (p.sparse)
-        hipLaunchKernelGGL((filter_final_kernel<true>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+        hipLaunchKernelGGL((filter_final_kernel<true, KB>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
                            mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
     else
-        hipLaunchKernelGGL((filter_final_kernel<false>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+        hipLaunchKernelGGL((filter_final_kernel<false, KB>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
                            mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
     const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
-    hipLaunchKernelGGL(filter_slow_kernel, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
+    hipLaunchKernelGGL(filter_slow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
                        n_flagged, out_idx, out_val, want, parts);
     if (want > 1)
         hipLaunchKernelGGL(filter_slow_merge_kernel, dim3(64), dim3(256), 0, s, flist, n_flagged, want, parts, k, out_idx,
                            out_val);
     MMREC_RETURN_LAUNCH_STATUS();
+}
+}  // namespace
+
+int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, int kd, const int32_t* mask_rowptr,
+                         const int32_t* mask_col, int k, int64_t* out_idx, float* out_val, void* workspace,
+                         const void* prepared, hipStream_t s) {
+    return kd == 64 ? filter_launch_kb<1>(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s)
+                    : filter_launch_kb<2>(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
 }

@@ -815,6 +815,37 @@ def test_topk_filter_k_up_to_128(ops, dev, nq, nc, k):
         ops.score_topk(D(Q, dev), D(C[:3000], dev), k)                   # below 4096 candidates: 64 is the limit
 
 
+@pytest.mark.parametrize("nq,nc,k", [(600, 7050, 50), (300, 40_037, 50), (64, 70_001, 100), (517, 4096, 20)])
+def test_topk_filter_rows_of_128(ops, dev, nq, nc, k):
+    """kd = 128 on the fp16 filter path (VBPR / PGL / SELFCFED_LGN rank 128-wide rows: vbpr.py:100-106; they went through the
+    materialised fp32 path before): each 64-candidate stage is walked as two 64-column tiles into the same accumulators, the
+    exact refinement sums chunk j + chunk j + 16 first and then the kd = 64 tree.  Rows of bits and word lists, ties, a heavy
+    user (slow queue), embeddings with a large common component, query rows of very different norms -- vs orc.mask_topk and
+    vs the materialised path; prepared candidates give the same bits."""
+    rng = np.random.default_rng(nq + nc + k)
+    Q = (rng.standard_normal((nq, 128)) * 0.2 + 0.3).astype(np.float32)
+    C = (rng.standard_normal((nc, 128)) * 0.2 + 0.3).astype(np.float32)
+    Q[11] *= np.float32(2.0) ** -40
+    Q[12] *= np.float32(2.0) ** 20
+    C[100:100 + 300 * 7:7] = 0.5                       # 300 identical candidates ...
+    Q[5] = 1.0                                         # ... that are this query's best
+    heavy = rng.choice(nc, 900, replace=False)
+    rows = np.concatenate([rng.integers(0, nq, 10 * nq), np.repeat(9, heavy.shape[0])])
+    cols = np.concatenate([rng.integers(0, nc, 10 * nq), heavy])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    idx = _topk_check(ops, dev, Q, C, k, mask, exact_gap=2e-5)
+    masked5 = set(mask[1][mask[0] == 5].tolist())
+    assert idx[5].tolist() == [c for c in range(100, 100 + 300 * 7, 7) if c not in masked5][:k]
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    Qd, Cd = D(Q, dev), D(C, dev)
+    a = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)
+    b = ops.score_topk(Qd, ops.TopkCandidates(Cd), k, rp, col, return_values=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    m = ops.score_topk(Qd, Cd, min(k, 64), rp, col, return_values=True, use_filter=False)
+    np.testing.assert_allclose(a[1][:, :min(k, 64)].cpu().numpy(), m[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("nq,nc", [(700, 7050), (300, 40_037), (100, 3000)])
 def test_topk_prepared_candidates_identical(ops, dev, nq, nc):
     """mmrec_score_topk_prepared_f32 (ABI 7): the candidate side of the fp16 filter computed ONCE (hip_ops.TopkCandidates)

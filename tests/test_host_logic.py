@@ -83,7 +83,8 @@ def test_native_random_sample_range_equals_cpython():
         assert a == random.sample(range(n), k) and random.getstate() == state_a, (n, k)
 
 
-def test_fp16_filter_error_bound_holds():
+@pytest.mark.parametrize("kd", [64, 128])
+def test_fp16_filter_error_bound_holds(kd):
     """The error bound the fp16 top-K filter (csrc/topk_filter.hip) relies on, restated in numpy: candidates centred by
     their mean row and scaled by ONE power of two, every query row scaled by ITS OWN power of two (thresholds are per
     query), both into fp16's normal range and rounded to fp16:
@@ -92,8 +93,11 @@ def test_fp16_filter_error_bound_holds():
     in the scaled / centred units of the approximate score.  Cases: embeddings sharing a large common component (as
     after LightGCN propagation), tiny / huge magnitudes, and -- round-1 review -- HETEROGENEOUS query norms (rows scaled
     by 2^-20 .. 2^-34, an all-zero row, a huge row), which one global query scale pushed into fp16 subnormals
-    (err / eps up to 71 there), plus candidates of very different norms and an almost constant candidate set."""
+    (err / eps up to 71 there), plus candidates of very different norms and an almost constant candidate set.
+    kd = 128 (round 3: VBPR / PGL / SELFCFED_LGN evaluate 128-wide rows): the two kd-dependent terms scale as the kernel
+    scales them -- the exact scores' fp32 rounding with kd / 64, the subnormal term with sqrt(kd / 64)."""
     rng = np.random.default_rng(0)
+    kb = kd / 64.0
 
     def scale_of(mx):                       # fp16_scale(): brings |x| <= mx below 2^13
         mx = np.asarray(mx, dtype=np.float32)
@@ -102,17 +106,17 @@ def test_fp16_filter_error_bound_holds():
 
     cases = []
     for common, mag in ((0.0, 0.2), (5.0, 0.2), (0.0, 1e-4), (50.0, 30.0)):
-        Q = (rng.standard_normal((300, 64)) * mag + common).astype(np.float32)
-        C = (rng.standard_normal((2000, 64)) * mag + common).astype(np.float32)
+        Q = (rng.standard_normal((300, kd)) * mag + common).astype(np.float32)
+        C = (rng.standard_normal((2000, kd)) * mag + common).astype(np.float32)
         cases.append((Q, C))
     # heterogeneous query norms
-    Q = (rng.standard_normal((300, 64)) * 0.2).astype(np.float32)
+    Q = (rng.standard_normal((300, kd)) * 0.2).astype(np.float32)
     for r, e in enumerate((-20, -24, -28, -30, -34, -40, -60, -100, -126)):
         Q[r] *= np.float32(2.0) ** e
     Q[20] = 0.0
     Q[21] *= np.float32(1e30)
     Q[22, 1:] *= np.float32(2.0) ** -30                      # one dominant element, the rest far below it
-    C = (rng.standard_normal((2000, 64)) * 0.2).astype(np.float32)
+    C = (rng.standard_normal((2000, kd)) * 0.2).astype(np.float32)
     cases.append((Q, C))
     # heterogeneous candidate norms (rows far below the largest one) under the same queries
     C2 = C.copy()
@@ -120,8 +124,8 @@ def test_fp16_filter_error_bound_holds():
     C2[500:600] *= np.float32(2.0) ** -40
     cases.append((Q, C2))
     # an almost constant candidate set: the centred rows are ~1e-6 of the uncentred ones
-    C3 = (5.0 + rng.standard_normal((2000, 64)) * 1e-6).astype(np.float32)
-    cases.append(((rng.standard_normal((300, 64)) * 0.2).astype(np.float32), C3))
+    C3 = (5.0 + rng.standard_normal((2000, kd)) * 1e-6).astype(np.float32)
+    cases.append(((rng.standard_normal((300, kd)) * 0.2).astype(np.float32), C3))
     worst = 0.0
     for ci, (Q, C) in enumerate(cases):
         mean = C.sum(0, dtype=np.float32) / np.float32(C.shape[0])
@@ -135,8 +139,8 @@ def test_fp16_filter_error_bound_holds():
         exact = ((Q.astype(np.float64) * sq.astype(np.float64)) @ (C.astype(np.float64) - mean.astype(np.float64)).T) * float(sc)
         qn = np.linalg.norm(Qh.astype(np.float64), axis=1) * 1.0005
         cmax = np.linalg.norm(Ch.astype(np.float64), axis=1).max() * 1.0005
-        eps = qn * (1.0e-3 * cmax + 4.0e-6 * (cmax + float(sc) * np.linalg.norm(mean.astype(np.float64)))) + \
-            2.4e-7 * (qn + cmax)
+        eps = qn * (1.0e-3 * cmax + 4.0e-6 * kb * (cmax + float(sc) * np.linalg.norm(mean.astype(np.float64)))) + \
+            2.4e-7 * np.sqrt(kb) * (qn + cmax)
         err = np.abs(approx - exact).max(axis=1)
         assert np.all(err <= eps), (ci, float((err / np.maximum(eps, 1e-300)).max()))
         worst = max(worst, float((err[eps > 0] / eps[eps > 0]).max()))

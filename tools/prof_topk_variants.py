@@ -53,15 +53,16 @@ def cases(dev):
         rp, col = hip_ops.mask_to_csr(np.stack([eu, ei]), nu, dev)
         out.append((shape, E[:nu].contiguous(), E[nu:].contiguous(), rp, col))
     gen = torch.Generator(device=dev).manual_seed(9)
-    for nq, nc in ((65536, 500000), (4096, 7050), (20000, 40000), (333, 33000)):
-        common = torch.randn(64, device=dev, generator=gen) * 0.05
-        Q = torch.randn(nq, 64, device=dev, generator=gen) * 0.03 + common
-        C = torch.randn(nc, 64, device=dev, generator=gen) * 0.03 + common
+    for nq, nc, kd in ((65536, 500000, 64), (4096, 7050, 64), (20000, 40000, 64), (333, 33000, 64),
+                       (65536, 500000, 128), (19445, 7050, 128)):
+        common = torch.randn(kd, device=dev, generator=gen) * 0.05
+        Q = torch.randn(nq, kd, device=dev, generator=gen) * 0.03 + common
+        C = torch.randn(nc, kd, device=dev, generator=gen) * 0.03 + common
         mrow = np.repeat(np.arange(nq), 8)
         mcol = np.random.default_rng(2).integers(0, nc, nq * 8)
         key = np.unique(mrow.astype(np.int64) * nc + mcol)
         rp, col = hip_ops.mask_to_csr(np.stack([key // nc, key % nc]), nq, dev)
-        out.append(("%dx%d" % (nq, nc), Q, C, rp, col))
+        out.append(("%dx%dx%d" % (nq, nc, kd), Q, C, rp, col))
     return out
 
 
