@@ -54,8 +54,8 @@ typedef __attribute__((ext_vector_type(8))) _Float16 half8;
 typedef __attribute__((ext_vector_type(16))) float acc16;
 
 constexpr int F_QWG = 256;     // queries per workgroup: 4 waves x 2 fragments x 32
-constexpr int F_CAPQ = 256;    // survivor slots per query over all ranges
-#ifndef MMREC_TF_P1S       // pass-1 stage stride: 0 = the default of filter_plan (1), n = forced (tools/prof_topk_variants.py)
+constexpr int F_CAPQ = 256;    // survivor slots per query over all ranges (512 where pass 1 looks at every second stage)
+#ifndef MMREC_TF_P1S       // pass-1 stage stride: 0 = the default of filter_plan, n = forced (tools/prof_topk_variants.py)
 #define MMREC_TF_P1S 0
 #endif
 #ifndef MMREC_TF_MINR      // tools/prof_topk_ranges.py sweeps the number of candidate ranges
@@ -69,7 +69,9 @@ constexpr int F_SLOW_PARTS = 4096;      // (query, split) partial top-k lists of
 constexpr int F_SLOW_SPLIT_NC = 65536;  // from this many candidates on a flagged query is split over 16 workgroups
 constexpr int F_MIN_NC = 4096;    // below: the materialised path is as fast (fixed launch costs)
 constexpr int F_SPARSE_NC = 32768;   // from this many candidates on pass 2 appends its NON-ZERO 64-bit words to a list
-constexpr int F_WCAP = 256;          // ... of this many (word index, word) entries per query (each holds >= 1 survivor)
+constexpr int F_WCAP = 256;          // ... of this many (word index, word) entries per query (each holds >= 1 survivor);
+constexpr int F_WCAP2 = 512;         // ... twice as many where pass 1 subsamples (filter_plan): ~2 x the survivors
+constexpr int F_P1S2_NC = 131072;    // from this many candidates on pass 1 walks every second stage
 constexpr int F_PF = 4;        // 64-candidate stages in flight per workgroup (register ring)
 constexpr int F_MASK_LDS = 512; // mask entries per query staged in LDS by the final kernel (>= F_MAXR * 32)
 
@@ -208,11 +210,12 @@ struct PassArgs {
     const uint4* Cs;      // [n_stages * 64][8]
     int nq, nc, n_stages, stages_per_range, n_groups;
     int p1_stride;        // pass 1 looks at every p1_stride-th stage of a range only (see filter_plan)
+    int wcap;             // SPARSE: entries per query in wlist (F_WCAP / F_WCAP2)
     unsigned* gkeys;      // pass 1 out: [nq][n_groups] monotone keys of the group maxima
     const float* thr;     // pass 2 in:  [nq]
     unsigned long long* bits;   // pass 2 out: [nq][ranges][2][stages_per_range / 2] pass / fail bits
     int* wcnt;            // pass 2 out, SPARSE: [nq] appended words (zeroed by the launcher)
-    uint4* wlist;         // pass 2 out, SPARSE: [nq][F_WCAP] (word index in the row above, 0, word lo, word hi)
+    uint4* wlist;         // pass 2 out, SPARSE: [nq][wcap] (word index in the row above, 0, word lo, word hi)
 };
 
 // The MFMAs of a stage are issued back to back (four independent accumulator chains, alternating): on gfx950 ANY
@@ -288,8 +291,8 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            if (ps[f] >= 0 && ps[f] < F_WCAP)
-                a.wlist[(size_t)(q0 + f * 32 + i) * F_WCAP + ps[f]] =
+            if (ps[f] >= 0 && ps[f] < a.wcap)
+                a.wlist[(size_t)(q0 + f * 32 + i) * a.wcap + ps[f]] =
                     make_uint4(pw[f], 0u, (unsigned)pb[f], (unsigned)(pb[f] >> 32));
             ps[f] = -1;
         }
@@ -683,15 +686,16 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     __syncthreads();   // `merged` / the lists are reused by the workgroup's next query
 }
 
-template <bool SPARSE, int KB>
+// CAP: survivor slots per query (= entries of its word list when SPARSE)
+template <bool SPARSE, int KB, int CAP>
 __global__ __launch_bounds__(256) void filter_final_kernel(
     const float* __restrict__ Q, const float* __restrict__ C, int nq, int nc, int k,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
     const unsigned long long* __restrict__ bits, const int* __restrict__ wcnt, const uint4* __restrict__ wlist,
     int n_ranges, int tiles_per_range, const int* __restrict__ flag,
     int* __restrict__ flist, int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
-    __shared__ unsigned long long s_l[4][F_CAPQ];   // (score, id) of the unmasked survivors
-    __shared__ int s_ids[4][F_CAPQ];
+    __shared__ unsigned long long s_l[4][CAP];   // (score, id) of the unmasked survivors
+    __shared__ int s_ids[4][CAP];
     __shared__ int s_mask[4][F_MASK_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
@@ -701,9 +705,9 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     const int gpr = tiles_per_range >> 2;
     // SPARSE: the query's appended (word index, word) entries instead of its row of words
     const int n_app = SPARSE ? wcnt[q] : 0;
-    const int n_words = SPARSE ? min(n_app, F_WCAP) : n_ranges * 2 * gpr;
+    const int n_words = SPARSE ? min(n_app, CAP) : n_ranges * 2 * gpr;
     const unsigned long long* row = SPARSE ? nullptr : bits + (size_t)q * n_words;
-    const uint4* ents = SPARSE ? wlist + (size_t)q * F_WCAP : nullptr;
+    const uint4* ents = SPARSE ? wlist + (size_t)q * CAP : nullptr;
     int wi_next = lane;       // index of the word `x_next` (SPARSE: read from the entry)
     auto word = [&](int e, int& wi) -> unsigned long long {
         if (SPARSE) {
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     for (int kb = 0; kb < KB; ++kb) qv[kb] = reinterpret_cast<const float4*>(Q)[(size_t)q * (16 * KB) + kb * 16 + (lane & 15)];
     const int fl = flag[q];
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
-    bool bad = fl != 0 || m > F_MASK_LDS || n_app > F_WCAP;
+    bool bad = fl != 0 || m > F_MASK_LDS || n_app > CAP;
     if (!bad) {
         // A: decode the pass / fail bits of pass 2 into candidate ids; stage the query's sorted mask list
         for (int e = lane; e < m; e += 64) s_mask[wave][e] = mask_col[m_lo + e];
@@ -743,21 +747,21 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
                     const int pz = __clzll((long long)x);          // 16 j + r
                     x &= ~(0x8000000000000000ull >> pz);
                     const int r = pz & 15, dst = n + __popcll(b & lt);
-                    if (dst < F_CAPQ) s_l[wave][dst] = (unsigned long long)(unsigned)(cbase + (pz >> 4) * 32 + (r & 3) + 8 * (r >> 2));
+                    if (dst < CAP) s_l[wave][dst] = (unsigned long long)(unsigned)(cbase + (pz >> 4) * 32 + (r & 3) + 8 * (r >> 2));
                 }
                 n += __popcll(b);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (n > F_CAPQ || n < k) bad = true;
-        int c[F_CAPQ / 64];
+        if (n > CAP || n < k) bad = true;
+        int c[CAP / 64];
 #pragma unroll
-        for (int u = 0; u < F_CAPQ / 64; ++u) c[u] = (!bad && lane + 64 * u < n) ? (int)s_l[wave][lane + 64 * u] : -1;
+        for (int u = 0; u < CAP / 64; ++u) c[u] = (!bad && lane + 64 * u < n) ? (int)s_l[wave][lane + 64 * u] : -1;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // B: drop padding and masked ids, compact the rest
         int valid = 0;
 #pragma unroll
-        for (int u = 0; u < F_CAPQ / 64; ++u) {
+        for (int u = 0; u < CAP / 64; ++u) {
             bool ok = c[u] >= 0 && c[u] < nc;
             if (ok && m > 0) {
                 int lo = 0, hi = m;
@@ -867,6 +871,7 @@ __global__ __launch_bounds__(256) void filter_slow_merge_kernel(const int* __res
 struct FilterPlan {
     int n_stages, qblocks, nq_pad, R, spr, n_groups;   // spr: 64-candidate stages per range
     int p1_stride;                                     // pass 1 walks every p1_stride-th stage
+    int wcap;                                          // sparse: word-list entries per query
     bool sparse;                                       // pass 2 -> word lists instead of rows of words
     size_t bits_bytes;                                 // the region pass 2 writes (rows, or counters + lists)
 };
@@ -892,13 +897,17 @@ inline FilterPlan filter_plan(int nq, int nc) {
     }
     p.n_groups = 32 * p.R;
     p.sparse = nc >= F_SPARSE_NC;
-    // pass 1 on a subset of the candidates (every S-th stage) is a probe, not a default.  Measured (profiles/
-    // r03_topk_pass1_stride_ab.log, r03_bench_line_p1s2.json): with i.i.d. embeddings S = 2 takes a 65,536 x 500,000 block from
-    // 8.3 to 6.8 ms (the bound sits ~2 x as deep in the ranking, ~130 survivors per query); with the SMOOTHED embeddings a
-    // propagation produces the scores are packed so densely below the bound that the survivor lists overflow their 256
-    // slots and the queries fall to the exact slow path: the same block took 250 ms.  Correct either way, 30 x slower.
-    p.p1_stride = MMREC_TF_P1S > 0 ? MMREC_TF_P1S : 1;
-    p.bits_bytes = p.sparse ? ((((size_t)nq * 4 + 255) & ~(size_t)255) + (size_t)nq * F_WCAP * 16)
+    // Pass 1 on every second stage of large candidate sets: the maxima of HALF the candidates still bound the (k + m)-th best
+    // score from below (k + m distinct candidates reach the bound), about twice as deep in the ranking -- ~2 (k + m) survivors
+    // plus what the 2 eps margin lets through -- for half the MFMAs of the pass.  The word lists and the final kernel's
+    // survivor slots are twice as long there (F_WCAP2): with 256 slots the SMOOTHED embeddings a propagation produces (one
+    // candidate of huge norm sets eps: ~120 survivors per query at stride 1, ~245 at stride 2; tools/topk_survivor_model.py)
+    // overflowed for a third of the queries and those fell to the exact slow path -- 30 x slower (profiles/
+    // r03_topk_pass1_stride_ab.log, r03_bench_line_p1s2.json).  Small candidate sets keep stride 1: their passes are short and
+    // heavy users (k + m near the slot count) are relatively more frequent in real data.
+    p.p1_stride = MMREC_TF_P1S > 0 ? MMREC_TF_P1S : (p.sparse && nc >= F_P1S2_NC ? 2 : 1);
+    p.wcap = p.p1_stride >= 2 ? F_WCAP2 : F_WCAP;
+    p.bits_bytes = p.sparse ? ((((size_t)nq * 4 + 255) & ~(size_t)255) + (size_t)nq * p.wcap * 16)
                             : (size_t)nq * p.R * p.spr * 8;
     return p;
 }
@@ -960,7 +969,7 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     int* flist = reinterpret_cast<int*>(ws);           ws += al256f((size_t)nq * 4);
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws);   // [nq][R][2][spr / 2], or:
     int* wcnt = reinterpret_cast<int*>(ws);                                 // sparse: [nq] counters, then
-    uint4* wlist = reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4));   //         [nq][F_WCAP] entries
+    uint4* wlist = reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4));   //         [nq][wcap] entries
     ws += al256f(p.bits_bytes);
     unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][128]
     if (!prepared) {
@@ -974,7 +983,7 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     // the query-side conversion also zeroes the call's counters (slow-queue length, word-list lengths): no memset launches
     hipLaunchKernelGGL((filter_convert_kernel<false, 8 * KB>), dim3(p.nq_pad * 8 * KB / 256), dim3(256), 0, s, Q, nq, p.nq_pad,
                        stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
-    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, gkeys, thr, bits, wcnt, wlist};
+    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist};
     const dim3 grid(p.qblocks, p.R);
     hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
@@ -984,11 +993,14 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     else
         hipLaunchKernelGGL((filter_pass_kernel<true, false, KB>), grid, dim3(256), 0, s, a);
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
-    if (p.sparse)
-        hipLaunchKernelGGL((filter_final_kernel<true, KB>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+    if (p.sparse && p.wcap == F_WCAP2)
+        hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP2>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+    else if (p.sparse)
+        hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
                            mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
     else
-        hipLaunchKernelGGL((filter_final_kernel<false, KB>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
+        hipLaunchKernelGGL((filter_final_kernel<false, KB, F_CAPQ>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
                            mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
     const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
     hipLaunchKernelGGL(filter_slow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,

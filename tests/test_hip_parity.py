@@ -788,6 +788,39 @@ def test_topk_filter_word_lists(ops, dev, nq, nc):
     assert np.array_equal(a[0].cpu().numpy(), idx)
 
 
+@pytest.mark.parametrize("nq,nc,k,kd", [(200, 200_003, 50, 64), (64, 131_072, 100, 64), (130, 150_001, 20, 128)])
+def test_topk_filter_subsampled_pass1(ops, dev, nq, nc, k, kd):
+    """>= 131,072 candidates: pass 1 walks every second 64-candidate stage (its maxima over half the candidates still bound
+    the (k + m)-th best from below), so ~2 (k + m) candidates survive into 512-entry word lists.  Embeddings with a common
+    component and ONE candidate of 20 x the typical norm (it sets eps: what a propagated low-degree item does at config 5),
+    a query whose best 1,200 candidates tie (> 512 words: overflow -> slow queue), heavy users with k + m below and above what
+    the lists hold, against the oracle; the materialised path agrees; two calls are bitwise identical."""
+    rng = np.random.default_rng(nq + nc + k)
+    Q = (rng.standard_normal((nq, kd)) * 0.2 + 0.1).astype(np.float32)
+    C = (rng.standard_normal((nc, kd)) * 0.2 + 0.1).astype(np.float32)
+    C[77] *= 20.0
+    C[5000:5000 + 1200 * 80:80] = 0.7
+    Q[7] = 1.0
+    heavy = {11: 150, 13: 420, 19: 3000}
+    rows = np.concatenate([rng.integers(0, nq, 10 * nq)] + [np.repeat(q, n) for q, n in heavy.items()])
+    cols = np.concatenate([rng.integers(0, nc, 10 * nq)] + [rng.choice(nc, n, replace=False) for n in heavy.values()])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    idx = _topk_check(ops, dev, Q, C, k, mask, exact_gap=2e-5 if kd > 64 else 1e-5)
+    masked7 = set(mask[1][mask[0] == 7].tolist())
+    if 77 not in masked7:
+        assert idx[7, 0] == 77                                    # 20 x the norm of a tie member's row, same direction on average
+    ties = [c for c in range(5000, 5000 + 1200 * 80, 80) if c not in masked7]
+    assert [c for c in idx[7].tolist() if c != 77][:k - 1] == ties[:k - 1]
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    Qd, Cd = D(Q, dev), D(C, dev)
+    a = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)
+    b = ops.score_topk(Qd, ops.TopkCandidates(Cd), k, rp, col, return_values=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[0].cpu().numpy(), idx)
+    m = ops.score_topk(Qd, Cd, min(k, 64), rp, col, return_values=True, use_filter=False)
+    np.testing.assert_allclose(a[1][:, :min(k, 64)].cpu().numpy(), m[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("nq,nc,k", [(600, 7050, 100), (300, 40_037, 128), (64, 70_001, 65), (200, 4096, 100)])
 def test_topk_filter_k_up_to_128(ops, dev, nq, nc, k):
     """k = 65..128 on the fp16 filter path (kd = 64, >= 4096 candidates; `topk: [10, 20, 50, 100]` evaluates fused instead

@@ -15,8 +15,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
-    "current": [],                                # the tree as it is
-    "occ3": ["-DMMREC_TF_OCC3=1"],                # word-list pass 2 at three workgroups per CU (168 VGPRs, 12 spilled)
+    "current": [],                                # the tree as it is (pass 1 on every second stage from 131,072 candidates on)
+    "p1s1": ["-DMMREC_TF_P1S=1"],                 # pass 1 on every stage everywhere (the round-2 behaviour)
 }
 
 
@@ -52,6 +52,19 @@ def cases(dev):
         E = hip_ops.lightgcn_mean(g, E0, 2)                      # what a model ranks with
         rp, col = hip_ops.mask_to_csr(np.stack([eu, ei]), nu, dev)
         out.append((shape, E[:nu].contiguous(), E[nu:].contiguous(), rp, col))
+    if os.environ.get("TFW_C5", "1") != "0":                     # what bench.py's c5_full_eval ranks: E = A^3 X0 at config-5 size
+        nu, ni, eu, ei = synth.shaped_edges("c5", seed=0)
+        r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+        g = hip_ops.CsrGraph.from_coo_device(torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
+                                             torch.from_numpy(v).to(dev), nu + ni, nu + ni, symmetric=True)
+        E = torch.rand(nu + ni, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) - 0.5
+        for _ in range(3):
+            E = hip_ops.spmm(g, E)
+        nq = 65536
+        sel = eu < nq                                            # edges are sorted by user
+        rp, col = hip_ops.mask_to_csr(np.stack([eu[sel], ei[sel]]), nq, dev)
+        out.append(("c5prop_65536x500000", E[:nq].contiguous(), E[nu:].contiguous(), rp, col))
+        del g
     gen = torch.Generator(device=dev).manual_seed(9)
     for nq, nc, kd in ((65536, 500000, 64), (4096, 7050, 64), (20000, 40000, 64), (333, 33000, 64),
                        (65536, 500000, 128), (19445, 7050, 128)):

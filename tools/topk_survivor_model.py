@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Host model of the fp16 top-K filter's survivor counts (topk_filter.hip: group maxima of pass 1 -> bound -> candidates within
+2 eps of it) on the embeddings the bench ranks with, for pass-1 stage strides 1 and 2.  No GPU needed.
+
+    python tools/topk_survivor_model.py c5        # E = A^3 X0 of the config-5 graph (what bench.py's c5_full_eval ranks)
+    python tools/topk_survivor_model.py sports    # layer mean of a 2-layer propagation at Amazon-Sports shape
+
+Round 3: at config 5 ONE candidate of norm 2.5 (median 0.11) sets eps, so ~120 candidates per query survive at
+stride 1 (63 without the margin) and ~245 at stride 2 -- more than the 256 slots the lists had for a third of the queries."""
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from mmrec_amd import synth  # noqa: E402
+
+
+def main(shape):
+    nu, ni, eu, ei = synth.shaped_edges(shape, seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    A = sp.coo_matrix((v, (r, c)), shape=(nu + ni, nu + ni)).tocsr()
+    rng = np.random.default_rng(0)
+    if shape == "c5":
+        E = rng.random((nu + ni, 64), dtype=np.float32) - 0.5
+        for _ in range(3):
+            E = A @ E
+    else:
+        b = np.sqrt(6.0 / (nu + 64)), np.sqrt(6.0 / (ni + 64))
+        E0 = np.concatenate([rng.uniform(-b[0], b[0], (nu, 64)), rng.uniform(-b[1], b[1], (ni, 64))]).astype(np.float32)
+        E, acc = E0, E0.copy()
+        for _ in range(2):
+            E = A @ E
+            acc += E
+        E = acc / 3
+    U, I = E[:nu], E[nu:]
+    mean = I.mean(0)
+    Ic = I - mean
+    cn = np.linalg.norm(Ic, axis=1)
+    cmax = cn.max()
+    print("centred candidate norms: median %.3g  p99 %.3g  max %.3g" % (np.median(cn), np.percentile(cn, 99), cmax))
+    qs = rng.choice(nu, 200, replace=False)
+    k = 50
+    deg = np.bincount(eu, minlength=nu)
+    n_stages = (ni + 63) // 64
+    n_ranges = 16
+    spr = (-(-n_stages // n_ranges) + 3) // 4 * 4
+    for S in (1, 2):
+        surv, plain, words = [], [], []
+        for q in qs:
+            s = Ic @ U[q]
+            m, qn = deg[q], np.linalg.norm(U[q])
+            eps = qn * (1.0e-3 * cmax + 4e-6 * (cmax + np.linalg.norm(mean))) + 2.4e-7 * (qn + cmax)
+            gm = np.full(32 * n_ranges, -np.inf)
+            for rg in range(n_ranges):
+                st = np.arange(rg * spr, min((rg + 1) * spr, ni // 64))[::S]
+                if len(st):
+                    gm[rg * 32:(rg + 1) * 32] = s[st[:, None] * 64 + np.arange(64)[None, :]].reshape(len(st), 2, 32).max(axis=(0, 1))
+            bound = np.sort(gm)[::-1][k + m - 1]
+            keep = s >= bound - 2 * eps
+            surv.append(int(keep.sum()))
+            plain.append(int((s >= bound).sum()))
+            words.append(len(np.unique(np.nonzero(keep)[0] // 64)))
+        surv, plain, words = np.array(surv), np.array(plain), np.array(words)
+        print("%s stride %d: survivors median %d p90 %d max %d (without the 2 eps margin: median %d); non-zero words median %d "
+              "max %d; k + m median %d; > 256: %.3f  > 512: %.3f" % (
+                  shape, S, np.median(surv), np.percentile(surv, 90), surv.max(), np.median(plain), np.median(words), words.max(),
+                  np.median(k + deg[qs]), (surv > 256).mean(), (surv > 512).mean()))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "c5")
