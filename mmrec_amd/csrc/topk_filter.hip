@@ -86,6 +86,16 @@ __device__ __forceinline__ float key2f(unsigned k) {
 // monotone keys at fixed word offsets: ST_CMAX = key(max |c_ij|), ST_NMAX = key(max norm of a converted, centred row).
 // (Queries are scaled row by row: nothing global to collect for them.)  kd = 64 or 128 floats per row.
 constexpr int ST_WORDS = 256, ST_CMAX = 252, ST_NMAX = 253;
+// Large candidate sets (>= F_P1S2_NC) CLIP the few rows of outlying norm: eps is proportional to the largest stored row norm,
+// and ONE low-degree item of 20 x the median norm (config 5 after three propagation layers: 2.5 against 0.11) doubled every
+// query's survivors.  The <= F_OUT_CAP rows whose norm lies in the topmost occupied bins of a norm histogram (bins = exponent
+// + 3 mantissa bits; tau = lower edge of the lowest such bin) are stored as f c', f = tau / |c'| < 1, and listed at ST_OUT0:
+//   * pass 1: a clipped row's approximate score s~ is within eps(tau) of f s.  Where the bound T >= eps (checked per query;
+//     otherwise the query goes to the slow queue) every group maximum >= T of a clipped row has f s >= 0, so s >= f s >= s~ -
+//     eps: still a lower bound of a real candidate's score;
+//   * pass 2 may miss a clipped row (its stored score is too small), so the final kernel ALWAYS rescores the listed rows.
+//   * the fp32 rounding of the EXACT scores (the 4e-6 term of eps) keeps the unclipped largest norm (ST_NMAX0).
+constexpr int F_OUT_CAP = 32, ST_NOUT = 200, ST_OUT0 = 201, ST_TAU = 240, ST_NMAX0 = 241, F_NHIST = 2048;
 // Grid: the 128-row slabs of C.
 __global__ __launch_bounds__(256) void filter_stats_kernel(const float* __restrict__ C, int nc, int kd4, float* __restrict__ stats) {
     __shared__ float4 s_sum[16][16];
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
     for (int o = W / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, W);
     // norms of the ROUNDED rows, inflated by the rounding (1 + 2^-11) and by sqrt's own error
     const float nrm = sqrtf(ss) * 1.0005f;
-    if (!CAND && ch == 0) norm[row] = nrm;
+    if (ch == 0 && (!CAND || norm)) norm[row] = nrm;     // candidates: only where the clipping below wants them
     if (CAND) {   // one atomic per workgroup (n_pad * W is a multiple of 256: no partial workgroups)
         __shared__ float s_mx[4];
         float mx = nrm;
@@ -202,6 +212,72 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
         __syncthreads();
         if (threadIdx.x == 0)
             atomicMax(maxnorm_key, f2key(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
+    }
+}
+
+// histogram of the converted candidate rows' norms (bin = float bits >> 20), 4096 rows per workgroup
+__global__ __launch_bounds__(256) void filter_norm_hist_kernel(const float* __restrict__ cnorm, int nc, int* __restrict__ hist) {
+    __shared__ int s_h[F_NHIST];
+    for (int b = threadIdx.x; b < F_NHIST; b += 256) s_h[b] = 0;
+    __syncthreads();
+    const int r0 = blockIdx.x * 4096;
+    for (int j = threadIdx.x; j < 4096; j += 256)
+        if (r0 + j < nc) atomicAdd(&s_h[__float_as_uint(cnorm[r0 + j]) >> 20], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < F_NHIST; b += 256)
+        if (s_h[b] != 0) atomicAdd(hist + b, s_h[b]);
+}
+
+// tau from the histogram (every workgroup computes it for itself), then the workgroup's 4096 rows: a row of norm >= tau is
+// listed and re-converted as f (c - mean) from the fp32 source (ONE rounding, like every other row).  W = kd / 8.
+template <int W>
+__global__ __launch_bounds__(256) void filter_clip_kernel(const float* __restrict__ C, int nc, const float* __restrict__ cnorm,
+                                                         const int* __restrict__ hist, float* __restrict__ stats,
+                                                         uint4* __restrict__ Cs) {
+    constexpr int KB = W / 8;
+    __shared__ int s_part[256];
+    __shared__ int s_b;
+    int part = 0;
+    for (int j = 0; j < 8; ++j) part += hist[threadIdx.x * 8 + j];
+    s_part[threadIdx.x] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {      // lowest bin b with #{rows in bins >= b} <= F_OUT_CAP (empty bins extend it downwards)
+        int cum = 0, b = F_NHIST, p = 255;
+        for (; p >= 0 && cum + s_part[p] <= F_OUT_CAP; --p) { cum += s_part[p]; b = 8 * p; }
+        if (p >= 0)
+            for (int j = 8 * p + 7; j >= 8 * p && cum + hist[j] <= F_OUT_CAP; --j) { cum += hist[j]; b = j; }
+        s_b = cum > 0 ? b : F_NHIST;
+    }
+    __syncthreads();
+    const int b = s_b;
+    if (b >= F_NHIST) return;                                  // nothing stands out: no clipping
+    const float tau = __uint_as_float((unsigned)b << 20);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats[ST_TAU] = tau;
+        reinterpret_cast<unsigned*>(stats)[ST_NMAX0] = reinterpret_cast<const unsigned*>(stats)[ST_NMAX];
+        reinterpret_cast<unsigned*>(stats)[ST_NMAX] = f2key(tau);       // every stored row norm is <= tau now
+    }
+    const float inv = 1.f / (float)nc;
+    const float scale = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
+    for (int j = threadIdx.x; j < 4096; j += 256) {
+        const int row = blockIdx.x * 4096 + j;
+        if (row >= nc) break;
+        const float nrm = cnorm[row];
+        if (!(nrm >= tau)) continue;
+        const int slot = atomicAdd(reinterpret_cast<int*>(stats) + ST_NOUT, 1);
+        reinterpret_cast<int*>(stats)[ST_OUT0 + slot] = row;             // slot < F_OUT_CAP by the choice of tau
+        const float f = scale * (tau * (1.f - 1.f / 512.f) / nrm);       // rounded norm <= tau (nrm already carries 1.0005)
+        for (int ch = 0; ch < W; ++ch) {
+            const float4 a = reinterpret_cast<const float4*>(C)[(size_t)row * (2 * W) + ch * 2];
+            const float4 c = reinterpret_cast<const float4*>(C)[(size_t)row * (2 * W) + ch * 2 + 1];
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            unsigned hb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                hb[e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)((x[e] - stats[ch * 8 + e] * inv) * f));
+            Cs[(((size_t)(row >> 6) * KB + (ch >> 3)) * 64 + (row & 63)) * 8 + (ch & 7)] =
+                make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+        }
     }
 }
 
@@ -235,6 +311,12 @@ struct PassArgs {
 //          again.  Instead a lane appends its NON-ZERO words to the query's list (one atomic slot counter per query;
 //          ~1 % of the words).  The append is software-pipelined: the atomic of one flush is consumed at the next, so no
 //          wave waits a memory round trip in the stage loop.  List order is arbitrary; the final kernel sorts anyway.
+#ifndef MMREC_TF_NOCLIP    // probe: no clipping of outlying candidate rows
+#define MMREC_TF_NOCLIP 0
+#endif
+#ifndef MMREC_TF_SCINIT    // probe: the word-list pass 2 starts its accumulators at -thr too
+#define MMREC_TF_SCINIT 0
+#endif
 #ifndef MMREC_TF_OCC3      // probe: three workgroups per CU for the word-list pass 2 (168 VGPRs: 12 spilled)
 #define MMREC_TF_OCC3 0
 #endif
@@ -267,7 +349,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     // C operand of a chain's first MFMA: 0 (pass 1) / -thr of the lane's query (pass 2: acc = score - thr, the pass / fail
     // bit is the accumulator's sign).  The word-list variant and the 128-wide rows have no 32 registers to spare for it (256
     // per wave at two workgroups per CU): they keep thr in one register per fragment and subtract per score.
-    constexpr bool CINIT = FILTER && !SPARSE && KB == 1;
+    constexpr bool CINIT = FILTER && (!SPARSE || MMREC_TF_SCINIT) && KB == 1;
     acc16 cinit[2];
     float thr[2];
     unsigned long long* brow[2];
@@ -285,6 +367,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     }
     // SPARSE: the append in flight per fragment (slot < 0: none)
     int ps[2] = {-1, -1};
+    int pcnt[2] = {0, 0};
     unsigned pw[2] = {0u, 0u};
     unsigned long long pb[2] = {0ull, 0ull};
     const unsigned wbase = (blockIdx.y * 2 + h) * (a.stages_per_range >> 1);
@@ -305,16 +388,20 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     // buffer.  The ring is eight named registers, not an array: an indexed private array went to scratch.
     uint4 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;
     ra0 = rb0 = ra1 = rb1 = ra2 = rb2 = ra3 = rb3 = make_uint4(0, 0, 0, 0);
-    auto gload = [&](int u, uint4& xa, uint4& xb) __attribute__((always_inline)) {     // micro-step u -> its tile
+    // EVERY load below is unconditional (past the range's end the last tile is loaded again): with `if (u + F_PF < u1)` around
+    // them the compiler could not count the loads in flight and drained them all (s_waitcnt vmcnt(0)) before every LDS
+    // store and every list append -- the four-tile prefetch distance was one stage's MFMAs in practice.
+    auto gload = [&](int uu, uint4& xa, uint4& xb) __attribute__((always_inline)) {     // micro-step u -> its tile
+        const int u = min(uu, u1 - 1);
         const int tv = u / KB, kb = u - tv * KB;
         const size_t o = (((size_t)(t0 + (tv - t0) * S) * KB + kb) * 64 + rr) * 8 + cc;
         xa = a.Cs[o];
         xb = a.Cs[o + 32 * 8];
     };
     gload(u0, ra0, rb0);
-    if (u0 + 1 < u1) gload(u0 + 1, ra1, rb1);
-    if (u0 + 2 < u1) gload(u0 + 2, ra2, rb2);
-    if (u0 + 3 < u1) gload(u0 + 3, ra3, rb3);
+    gload(u0 + 1, ra1, rb1);
+    gload(u0 + 2, ra2, rb2);
+    gload(u0 + 3, ra3, rb3);
     s_c[0][0][slot] = ra0;
     s_c[0][1][slot] = rb0;
     __syncthreads();
@@ -326,8 +413,10 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     // (fa, fb) = ring slot that held its tile (free now: refilled with u + F_PF), (na, nb) = slot of u + 1
     auto step = [&](int u, auto POS, uint4& fa, uint4& fb, const uint4& na, const uint4& nb) __attribute__((always_inline)) {
         constexpr int kb = decltype(POS)::value % KB;
-        if (u < u1) {         // uniform
-        if (u + F_PF < u1 && !(MMREC_TF_PROBE & 4)) gload(u + F_PF, fa, fb);
+        // (micro-steps past u1 -- the range's length rounded up to four -- run on the last tile again: its maxima are real
+        // candidates' scores once more, its pass / fail bits are dropped)
+        {
+        if (!(MMREC_TF_PROBE & 4)) gload(u + F_PF, fa, fb);
         half8 ca[4], cb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -348,10 +437,9 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
                 b1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb[s], qf[1][kb * 4 + s], b1, 0, 0, 0);
             }
         }
-        if (u + 1 < u1) {   // the next tile goes to the other LDS buffer while the matrix pipe drains
-            s_c[cur ^ 1][0][slot] = na;
-            s_c[cur ^ 1][1][slot] = nb;
-        }
+        // the next tile goes to the other LDS buffer while the matrix pipe drains
+        s_c[cur ^ 1][0][slot] = na;
+        s_c[cur ^ 1][1][slot] = nb;
         // a?[r] / b?[r] = score of candidate 64 t (+ 32) + (r & 3) + 8 (r >> 2) + 4 h for query q0 + 32 f + i
         if (kb != KB - 1) {
             // (more column blocks of this stage to come)
@@ -367,7 +455,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
             // the accumulators started at -thr: acc = score - thr, FAIL bit = its sign; w = (w << 1) | bit is ONE
             // v_alignbit_b32 per score (no subtraction); the word is inverted once per 32 scores
             w[0] = w[1] = 0u;
-            if (CINIT) {
+            if (CINIT && !SPARSE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(a0[r]), 31);
@@ -387,32 +475,43 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
                 // fragment: pass 2 was VALU co-bound at 8 VALU per MFMA (profiles/r03_topk_pmc.txt: MFMA pipe 53 % busy
                 // against 68 % in pass 1, whose per-score work is the max3 alone).
                 // bit = sign(thr' - score), thr' just below thr: score >= thr  <=>  score > thr'  <=>  sign bit set
-                float mx0 = -INFINITY, mx1 = -INFINITY;
+                // The decision is taken per QUARTER of a fragment's stage (32 queries x 16 candidates: 8 accumulators): with the
+                // ~160-250 survivors per query of a subsampled pass 1 a whole 32 x 64 block holds one every second stage (the
+                // skip then saves nothing: 32 max3 + half of 64 = the 64 it replaces), a 32 x 16 quarter in one stage of 7.
+                auto quarter = [&](const acc16& x, auto R0, float t, unsigned& wd) __attribute__((always_inline)) {
+                    constexpr int r0 = decltype(R0)::value;
+                    float m = __builtin_fmaxf(__builtin_fmaxf(x[r0], x[r0 + 1]), x[r0 + 2]);
+                    m = __builtin_fmaxf(__builtin_fmaxf(m, x[r0 + 3]), x[r0 + 4]);
+                    m = __builtin_fmaxf(__builtin_fmaxf(m, x[r0 + 5]), x[r0 + 6]);
+                    m = __builtin_fmaxf(m, x[r0 + 7]);
+                    if (CINIT) {            // (probe) x = score - thr: FAIL bit = its sign
+                        if (__ballot(!(m < 0.f)) != 0ull) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    mx0 = __builtin_fmaxf(__builtin_fmaxf(mx0, a0[r]), b0[r]);
-                    mx1 = __builtin_fmaxf(__builtin_fmaxf(mx1, a1[r]), b1[r]);
-                }
-                if (__ballot(mx0 > thr[0]) != 0ull) {
+                            for (int r = r0; r < r0 + 8; ++r) wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(x[r]), 31);
+                            wd ^= 0xffu;
+                        } else {
+                            wd <<= 8;
+                        }
+                    } else if (__ballot(m > t) != 0ull) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(thr[0] - a0[r]), 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(thr[0] - b0[r]), 31);
-                }
-                if (__ballot(mx1 > thr[1]) != 0ull) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) w[1] = __builtin_amdgcn_alignbit(w[1], __float_as_uint(thr[1] - a1[r]), 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) w[1] = __builtin_amdgcn_alignbit(w[1], __float_as_uint(thr[1] - b1[r]), 31);
-                }
+                        for (int r = r0; r < r0 + 8; ++r) wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(t - x[r]), 31);
+                    } else {
+                        wd <<= 8;
+                    }
+                };
+                using R0 = std::integral_constant<int, 0>;
+                using R8 = std::integral_constant<int, 8>;
+                quarter(a0, R0{}, thr[0], w[0]); quarter(a0, R8{}, thr[0], w[0]);
+                quarter(b0, R0{}, thr[0], w[0]); quarter(b0, R8{}, thr[0], w[0]);
+                quarter(a1, R0{}, thr[1], w[1]); quarter(a1, R8{}, thr[1], w[1]);
+                quarter(b1, R0{}, thr[1], w[1]); quarter(b1, R8{}, thr[1], w[1]);
             }
         }
         if (!(MMREC_TF_PROBE & 16)) __syncthreads();
         cur ^= 1;
-        } else if (FILTER && kb == KB - 1) {
-            w[0] = w[1] = 0u;
         }
         if (FILTER && kb == KB - 1) {      // a stage done: its 32 bits per fragment
+            if (u >= u1) w[0] = w[1] = 0u;
             bw[0] = (bw[0] << 32) | w[0];
             bw[1] = (bw[1] << 32) | w[1];
         }
@@ -427,7 +526,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
 #pragma unroll
             for (int f = 0; f < 2; ++f)
                 if (bw[f] != 0ull && q0 + f * 32 + i < a.nq) {
-                    ps[f] = atomicAdd(a.wcnt + q0 + f * 32 + i, 1);
+                    ps[f] = (MMREC_TF_PROBE & 64) ? pcnt[f]++ : atomicAdd(a.wcnt + q0 + f * 32 + i, 1);   // (probe 64: timing only, WRONG lists)
                     pw[f] = wbase + (unsigned)g;
                     pb[f] = bw[f];
                 }
@@ -447,6 +546,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     }
     static_assert(F_PF == 4 && (KB == 1 || KB == 2), "the step sequence above is written for a 4-slot ring and 1 or 2 column blocks");
     if (FILTER && SPARSE) commit();
+    if (FILTER && SPARSE && (MMREC_TF_PROBE & 64)) { atomicAdd(a.wcnt + q0 + i, pcnt[0]); atomicAdd(a.wcnt + q0 + 32 + i, pcnt[1]); }
     }
     if (!FILTER) {
 #pragma unroll
@@ -526,10 +626,14 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
         const float kb = (float)kd * (1.f / 64.f);
         // + 2^-25 sqrt(kd) (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
         // (sum |x_i| <= sqrt(kd) |x|; 2.4e-7 = 2^-22 for kd = 64)
-        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax + sc * sqrtf(mu))) +
+        const bool clipped = reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
+        const float cmax0 = clipped ? key2f(reinterpret_cast<const unsigned*>(stats)[ST_NMAX0]) : cmax;   // before clipping
+        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax0 + sc * sqrtf(mu))) +
                           2.4e-7f * sqrtf(kb) * (qnorm[q] + cmax);
-        thr[q] = key2f(cur) - 2.f * eps;
-        flag[q] = 0;
+        // clipped candidate rows are lower bounds of real scores only where the bound is >= eps
+        const bool ok = !clipped || key2f(cur) >= eps;
+        thr[q] = ok ? key2f(cur) - 2.f * eps : INFINITY;
+        flag[q] = ok ? 0 : 1;
     }
 }
 
@@ -693,7 +797,8 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
     const unsigned long long* __restrict__ bits, const int* __restrict__ wcnt, const uint4* __restrict__ wlist,
     int n_ranges, int tiles_per_range, const int* __restrict__ flag,
-    int* __restrict__ flist, int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    int* __restrict__ flist, int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+    const int* __restrict__ outl) {   // outl: nullptr, or {count, ids ...} of the clipped candidate rows (always rescored)
     __shared__ unsigned long long s_l[4][CAP];   // (score, id) of the unmasked survivors
     __shared__ int s_ids[4][CAP];
     __shared__ int s_mask[4][F_MASK_LDS];
@@ -753,8 +858,25 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (n > CAP || n < k) bad = true;
         int c[CAP / 64];
+        const int n_out = outl ? outl[0] : 0;
+        if (n_out > 0 && n <= CAP) {     // the clipped rows join the survivors unless pass 2 let them through already
+#pragma unroll
+            for (int u = 0; u < CAP / 64; ++u) c[u] = lane + 64 * u < n ? (int)s_l[wave][lane + 64 * u] : -1;
+            const int n0 = n;
+            for (int o = 0; o < n_out; ++o) {
+                const int id = outl[1 + o];
+                bool has = false;
+#pragma unroll
+                for (int u = 0; u < CAP / 64; ++u) has |= c[u] == id;
+                if (__ballot(has) == 0ull) {
+                    if (lane == 0 && n < CAP) s_l[wave][n] = (unsigned long long)(unsigned)id;
+                    ++n;
+                }
+            }
+            if (n != n0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (n > CAP || n < k) bad = true;
 #pragma unroll
         for (int u = 0; u < CAP / 64; ++u) c[u] = (!bad && lane + 64 * u < n) ? (int)s_l[wave][lane + 64 * u] : -1;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -912,6 +1034,7 @@ inline FilterPlan filter_plan(int nq, int nc) {
     return p;
 }
 inline size_t al256f(size_t x) { return (x + 255) & ~(size_t)255; }
+inline bool filter_clips(int nc) { return nc >= F_P1S2_NC && !MMREC_TF_NOCLIP; }
 
 }  // namespace
 
@@ -923,8 +1046,10 @@ bool topk64_filter_applicable(int nq, int nc, int kd, int k) {
 // -- depends on C only.  A caller that ranks several query blocks against the SAME table (the batches of one evaluation and
 // its valid / test pair, trainer.py:298-310: weights are frozen) prepares it once (`prepared`: 1 KiB of statistics + Cs) and
 // hands it to every call; without it a call prepares its own copy inside its workspace.
+// Layout: stats (1 KiB) | Cs | where rows are clipped (nc >= F_P1S2_NC): the rows' norms (fp32) | their histogram.
 size_t topk64_filter_prepared_bytes(int nc, int kd) {
-    return ST_WORDS * 4 + al256f((size_t)cdiv_i(nc, 64) * 64 * 2 * kd);
+    const size_t n_pad = (size_t)cdiv_i(nc, 64) * 64;
+    return ST_WORDS * 4 + al256f(n_pad * 2 * kd) + (filter_clips(nc) ? al256f(n_pad * 4) + F_NHIST * 4 : 0);
 }
 
 int topk64_filter_prepare(const float* C, int nc, int kd, void* prepared, hipStream_t s) {
@@ -932,15 +1057,27 @@ int topk64_filter_prepare(const float* C, int nc, int kd, void* prepared, hipStr
     float* stats = static_cast<float*>(prepared);
     uint4* Cs = reinterpret_cast<uint4*>(static_cast<char*>(prepared) + ST_WORDS * 4);
     unsigned* nmax = reinterpret_cast<unsigned*>(stats) + ST_NMAX;
+    const bool clip = filter_clips(nc);
+    const size_t n_pad = (size_t)n_stages * 64;
+    float* cnorm = clip ? reinterpret_cast<float*>(reinterpret_cast<char*>(Cs) + al256f(n_pad * 2 * kd)) : nullptr;
+    int* hist = clip ? reinterpret_cast<int*>(reinterpret_cast<char*>(cnorm) + al256f(n_pad * 4)) : nullptr;
     hipError_t e = hipMemsetAsync(stats, 0, ST_WORDS * 4, s);
     if (e != hipSuccess) return (int)e;
+    if (clip && (e = hipMemsetAsync(hist, 0, F_NHIST * 4, s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(filter_stats_kernel, dim3(cdiv_i(nc, 128)), dim3(256), 0, s, C, nc, kd / 4, stats);
     if (kd == 64)
         hipLaunchKernelGGL((filter_convert_kernel<true, 8>), dim3(n_stages * 64 * 8 / 256), dim3(256), 0, s, C, nc, n_stages * 64,
-                           stats, Cs, (float*)nullptr, nmax, (int*)nullptr, (int*)nullptr);
+                           stats, Cs, cnorm, nmax, (int*)nullptr, (int*)nullptr);
     else
         hipLaunchKernelGGL((filter_convert_kernel<true, 16>), dim3(n_stages * 64 * 16 / 256), dim3(256), 0, s, C, nc, n_stages * 64,
-                           stats, Cs, (float*)nullptr, nmax, (int*)nullptr, (int*)nullptr);
+                           stats, Cs, cnorm, nmax, (int*)nullptr, (int*)nullptr);
+    if (clip) {
+        hipLaunchKernelGGL(filter_norm_hist_kernel, dim3(cdiv_i(nc, 4096)), dim3(256), 0, s, cnorm, nc, hist);
+        if (kd == 64)
+            hipLaunchKernelGGL(filter_clip_kernel<8>, dim3(cdiv_i(nc, 4096)), dim3(256), 0, s, C, nc, cnorm, hist, stats, Cs);
+        else
+            hipLaunchKernelGGL(filter_clip_kernel<16>, dim3(cdiv_i(nc, 4096)), dim3(256), 0, s, C, nc, cnorm, hist, stats, Cs);
+    }
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
@@ -980,6 +1117,7 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     const float* stats = static_cast<const float*>(prepared);
     const unsigned* cmax = reinterpret_cast<const unsigned*>(prepared) + ST_NMAX;
     const uint4* Cs = reinterpret_cast<const uint4*>(static_cast<const char*>(prepared) + ST_WORDS * 4);
+    const int* outl = filter_clips(nc) ? static_cast<const int*>(prepared) + ST_NOUT : nullptr;   // clipped rows (prepare)
     // the query-side conversion also zeroes the call's counters (slow-queue length, word-list lengths): no memset launches
     hipLaunchKernelGGL((filter_convert_kernel<false, 8 * KB>), dim3(p.nq_pad * 8 * KB / 256), dim3(256), 0, s, Q, nq, p.nq_pad,
                        stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
@@ -995,13 +1133,13 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
     if (p.sparse && p.wcap == F_WCAP2)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP2>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl);
     else if (p.sparse)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl);
     else
         hipLaunchKernelGGL((filter_final_kernel<false, KB, F_CAPQ>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl);
     const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
     hipLaunchKernelGGL(filter_slow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
                        n_flagged, out_idx, out_val, want, parts);

@@ -791,27 +791,35 @@ def test_topk_filter_word_lists(ops, dev, nq, nc):
 @pytest.mark.parametrize("nq,nc,k,kd", [(200, 200_003, 50, 64), (64, 131_072, 100, 64), (130, 150_001, 20, 128)])
 def test_topk_filter_subsampled_pass1(ops, dev, nq, nc, k, kd):
     """>= 131,072 candidates: pass 1 walks every second 64-candidate stage (its maxima over half the candidates still bound
-    the (k + m)-th best from below), so ~2 (k + m) candidates survive into 512-entry word lists.  Embeddings with a common
-    component and ONE candidate of 20 x the typical norm (it sets eps: what a propagated low-degree item does at config 5),
+    the (k + m)-th best from below), so ~2 (k + m) candidates survive into 512-entry word lists, and the <= 32 candidate rows
+    of outlying norm are stored CLIPPED and always rescored (eps follows the largest stored norm).  Embeddings with a common
+    component, one candidate of 20 x the typical norm (what a propagated low-degree item is at config 5) and 40 more of 2.5-12 x,
     a query whose best 1,200 candidates tie (> 512 words: overflow -> slow queue), heavy users with k + m below and above what
     the lists hold, against the oracle; the materialised path agrees; two calls are bitwise identical."""
     rng = np.random.default_rng(nq + nc + k)
     Q = (rng.standard_normal((nq, kd)) * 0.2 + 0.1).astype(np.float32)
     C = (rng.standard_normal((nc, kd)) * 0.2 + 0.1).astype(np.float32)
     C[77] *= 20.0
+    big = rng.choice(np.arange(100_000, nc), 40, replace=False)      # more rows of outlying norm than the 32 the filter clips
+    C[big] *= rng.uniform(2.5, 12.0, (40, 1)).astype(np.float32)
     C[5000:5000 + 1200 * 80:80] = 0.7
     Q[7] = 1.0
+    Q[3] = 0.0                                                       # all scores tie at 0: bound below eps -> slow queue
+    Q[5] = -Q[5]                                                     # (the outliers are this query's WORST candidates)
     heavy = {11: 150, 13: 420, 19: 3000}
-    rows = np.concatenate([rng.integers(0, nq, 10 * nq)] + [np.repeat(q, n) for q, n in heavy.items()])
-    cols = np.concatenate([rng.integers(0, nc, 10 * nq)] + [rng.choice(nc, n, replace=False) for n in heavy.values()])
+    rows = np.concatenate([rng.integers(0, nq, 10 * nq)] + [np.repeat(q, n) for q, n in heavy.items()] + [np.repeat(21, 20)])
+    cols = np.concatenate([rng.integers(0, nc, 10 * nq)] + [rng.choice(nc, n, replace=False) for n in heavy.values()] +
+                          [big[:20]])                                # a query with half the outliers masked
     key = np.unique(rows.astype(np.int64) * nc + cols)
     mask = np.stack([key // nc, key % nc])
     idx = _topk_check(ops, dev, Q, C, k, mask, exact_gap=2e-5 if kd > 64 else 1e-5)
     masked7 = set(mask[1][mask[0] == 7].tolist())
-    if 77 not in masked7:
-        assert idx[7, 0] == 77                                    # 20 x the norm of a tie member's row, same direction on average
+    outl = set(big.tolist()) | {77}
     ties = [c for c in range(5000, 5000 + 1200 * 80, 80) if c not in masked7]
-    assert [c for c in idx[7].tolist() if c != 77][:k - 1] == ties[:k - 1]
+    rest = [c for c in idx[7].tolist() if c not in outl]           # behind the outliers that beat them: the ties, lowest ids first
+    assert len(rest) >= k - 41 and rest == ties[:len(rest)]
+    masked3 = set(mask[1][mask[0] == 3].tolist())
+    assert idx[3].tolist() == [c for c in range(k + len(masked3)) if c not in masked3][:k]
     rp, col = ops.mask_to_csr(mask, nq, dev)
     Qd, Cd = D(Q, dev), D(C, dev)
     a = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)

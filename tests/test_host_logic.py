@@ -147,6 +147,55 @@ def test_fp16_filter_error_bound_holds(kd):
     assert worst > 1e-3      # the bound is a bound, not a vacuous one
 
 
+def test_fp16_filter_clipped_rows_stay_lower_bounds():
+    """Round 3: candidate sets of >= 131,072 rows CLIP their few rows of outlying norm (filter_clip_kernel): eps is
+    proportional to the largest stored row norm, and one row of 20 x the median norm doubled every query's survivors at
+    config 5.  Restated: norm histogram over float bits >> 20, tau = lower edge of the lowest bin with <= 32 rows in the bins
+    from it upwards, rows of norm >= tau stored as fp16(f c'), f = tau (1 - 2^-9) / norm.  What the kernels' argument needs:
+    (a) <= 32 rows are clipped and every stored row norm is <= tau;  (b) a clipped row's approximate score is within eps(tau)
+    of f x its exact score, so wherever the approximate score is >= eps (the bound kernel checks T >= eps) the exact score
+    is >= approx - eps: the group maxima of pass 1 stay lower bounds of real scores;  (c) unclipped rows keep the plain bound
+    with tau in place of the largest norm."""
+    rng = np.random.default_rng(3)
+    kd, nc = 64, 140_000
+    C = (rng.standard_normal((nc, kd)) * 0.1 + 0.05).astype(np.float32)
+    big = rng.choice(nc, 20, replace=False)
+    C[big] *= rng.uniform(3.0, 25.0, (20, 1)).astype(np.float32)
+    Q = (rng.standard_normal((200, kd)) * 0.3).astype(np.float32)
+    mean = C.sum(0, dtype=np.float32) / np.float32(nc)
+    sc = np.float32(2.0 ** (13 - np.frexp(np.float32(2.0 * np.abs(C).max()))[1]))
+    sq = (2.0 ** (13 - np.frexp(np.abs(Q).max(axis=1))[1])).astype(np.float32)[:, None]
+    Ch = ((C - mean) * sc).astype(np.float16)
+    norms = (np.linalg.norm(Ch.astype(np.float32), axis=1) * np.float32(1.0005)).astype(np.float32)
+    bins = norms.view(np.uint32) >> 20
+    hist = np.bincount(bins, minlength=2048)
+    cum, b = 0, 2048
+    for j in range(2047, -1, -1):
+        if cum + hist[j] > 32:
+            break
+        cum, b = cum + hist[j], j
+    assert 0 < cum <= 32
+    tau = np.array([b << 20], dtype=np.uint32).view(np.float32)[0]
+    out = norms >= tau
+    assert out.sum() == cum
+    f = (sc * (tau * np.float32(1.0 - 1.0 / 512.0) / norms[out])).astype(np.float32)[:, None]
+    Ch[out] = ((C[out] - mean) * f).astype(np.float16)
+    stored = np.linalg.norm(Ch.astype(np.float64), axis=1) * 1.0005
+    assert stored.max() <= tau                                                            # (a)
+    Qh = (Q * sq).astype(np.float16)
+    qn = np.linalg.norm(Qh.astype(np.float64), axis=1) * 1.0005
+    eps = qn * (1.0e-3 * tau + 4.0e-6 * (float(norms.max()) + float(sc) * np.linalg.norm(mean.astype(np.float64)))) + 2.4e-7 * (qn + tau)
+    approx = Qh.astype(np.float64) @ Ch.astype(np.float64).T
+    exact = ((Q.astype(np.float64) * sq.astype(np.float64)) @ (C.astype(np.float64) - mean.astype(np.float64)).T) * float(sc)
+    ratio = (f[:, 0].astype(np.float64) / float(sc))                                      # f / scale < 1
+    assert np.all(ratio < 1.0)
+    assert np.all(np.abs(approx[:, out] - exact[:, out] * ratio[None, :]) <= eps[:, None])          # (b)
+    pos = approx[:, out] >= eps[:, None]
+    assert np.all((exact[:, out] >= approx[:, out] - eps[:, None])[pos])
+    assert np.all(np.abs(approx[:, ~out] - exact[:, ~out]) <= eps[:, None])               # (c)
+    assert tau < 0.5 * norms.max()                                                        # the clipping bought something
+
+
 def test_config_helpers_for_added_keys():
     """eval_batch_size(): the reference's 4096 unless the fused evaluation runs on the GPU; lazy_adam_enabled(): off on
     the CPU / without the fused Adam / with gradient clipping, automatic only for large tables, forced by True / False;

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
     "current": [],                                # the tree as it is (pass 1 on every second stage from 131,072 candidates on)
-    "p1s1": ["-DMMREC_TF_P1S=1"],                 # pass 1 on every stage everywhere (the round-2 behaviour)
+    "scinit": ["-DMMREC_TF_SCINIT=1"],            # word-list pass 2 with accumulators started at -thr
+    "p1s1": ["-DMMREC_TF_P1S=1", "-DMMREC_TF_NOCLIP=1"],    # pass 1 on every stage everywhere, no clipping (the round-2 behaviour)
 }
 
 
@@ -76,7 +77,8 @@ def cases(dev):
         key = np.unique(mrow.astype(np.int64) * nc + mcol)
         rp, col = hip_ops.mask_to_csr(np.stack([key // nc, key % nc]), nq, dev)
         out.append(("%dx%dx%d" % (nq, nc, kd), Q, C, rp, col))
-    return out
+    only = os.environ.get("TFW_ONLY")                            # e.g. TFW_ONLY=c5prop under rocprofv3
+    return [c for c in out if only is None or c[0].startswith(only)]
 
 
 def run_one():
