@@ -579,6 +579,10 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
         if (lane == 0) { thr[q] = INFINITY; flag[q] = 1; }
         return;
     }
+    if (qnorm[q] == 0.f) {       // an all-zero query row (a user without interactions after propagation): every score is exactly 0
+        if (lane == 0) { thr[q] = INFINITY; flag[q] = 2; }     // -> the final kernel writes the k lowest unmasked ids itself
+        return;
+    }
     unsigned key[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -833,6 +837,23 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     for (int kb = 0; kb < KB; ++kb) qv[kb] = reinterpret_cast<const float4*>(Q)[(size_t)q * (16 * KB) + kb * 16 + (lane & 15)];
     const int fl = flag[q];
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
+    if (fl == 2 && m <= F_MASK_LDS) {
+        // all scores tie at 0 (zero query row; nc - m >= k is the bound kernel's condition): ties go to the lower id, so the
+        // answer is the k lowest unmasked ids -- the j-th of them is j + #{i : mask[i] - i <= j} (mask sorted ascending).
+        // Through the slow queue each such query cost a 500K-candidate scan (0.4 ms per 65,536-query block at config 5).
+        for (int e = lane; e < m; e += 64) s_mask[wave][e] = mask_col[m_lo + e];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (int j = lane; j < k; j += 64) {
+            int lo = 0, hi = m;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_mask[wave][mid] - mid <= j) lo = mid + 1; else hi = mid;
+            }
+            out_idx[(size_t)q * k + j] = (int64_t)(j + lo);
+            if (out_val) out_val[(size_t)q * k + j] = 0.f;
+        }
+        return;
+    }
     bool bad = fl != 0 || m > F_MASK_LDS || n_app > CAP;
     if (!bad) {
         // A: decode the pass / fail bits of pass 2 into candidate ids; stage the query's sorted mask list
