@@ -314,9 +314,6 @@ struct PassArgs {
 #ifndef MMREC_TF_NOCLIP    // probe: no clipping of outlying candidate rows
 #define MMREC_TF_NOCLIP 0
 #endif
-#ifndef MMREC_TF_PFR       // 0: operands read from LDS at the start of their own micro-step (the pre-round-3 pipeline)
-#define MMREC_TF_PFR 1
-#endif
 #ifndef MMREC_TF_SCINIT    // probe: the word-list pass 2 starts its accumulators at -thr too
 #define MMREC_TF_SCINIT 0
 #endif
@@ -327,11 +324,7 @@ struct PassArgs {
 // candidates out tile by tile), accumulating into the same accumulators; the per-score work runs once per stage.
 template <bool FILTER, bool SPARSE, int KB>
 __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) void filter_pass_kernel(const PassArgs a) {
-    // Operands of micro-step u + 1 are read from LDS into a second register set DURING micro-step u (PFR), so the 16 MFMAs
-    // of a step issue right after the barrier instead of behind an LDS round trip; tile u + 2 is written meanwhile, hence
-    // three LDS buffers.  The two instantiations without 32 spare registers at two workgroups per CU keep the two-buffer form.
-    constexpr bool PFR = MMREC_TF_PFR && !(FILTER && !SPARSE && KB == 1) && !(!FILTER && KB == 2);
-    __shared__ uint4 s_c[PFR ? 3 : 2][2][256];   // [buffer][32-row half of the tile][row * 8 + swizzled chunk]
+    __shared__ uint4 s_c[2][2][256];   // [buffer][32-row half of the tile][row * 8 + swizzled chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * F_QWG + wave * 64;
@@ -411,36 +404,22 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     gload(u0 + 3, ra3, rb3);
     s_c[0][0][slot] = ra0;
     s_c[0][1][slot] = rb0;
-    if (PFR) {
-        s_c[1][0][slot] = ra1;
-        s_c[1][1][slot] = rb1;
-    }
     __syncthreads();
     int cur = 0;
-    half8 oa[2][4], ob[2][4];       // PFR: operand sets of the even / odd micro-steps
-    if (PFR) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            oa[0][s] = __builtin_bit_cast(half8, s_c[0][0][i * 8 + ((h * 4 + s) ^ sw)]);
-            ob[0][s] = __builtin_bit_cast(half8, s_c[0][1][i * 8 + ((h * 4 + s) ^ sw)]);
-        }
-    }
     unsigned w[2] = {0u, 0u};   // pass 2: pass / fail bits of the current stage, per fragment
     unsigned long long bw[2] = {0ull, 0ull};
     acc16 a0 = cinit[0], a1 = cinit[1], b0 = cinit[0], b1 = cinit[1];   // a: rows 0..31 of the stage, b: 32..63; 0 / 1: query fragment
     // one micro-step u at position POS of the unrolled sequence (column block kb = POS % KB: a range starts at an even u);
-    // (fa, fb) = ring slot that held its tile (free now: refilled with u + F_PF), (na, nb) = slot of u + 1 (PFR: of u + 2)
+    // (fa, fb) = ring slot that held its tile (free now: refilled with u + F_PF), (na, nb) = slot of u + 1
     auto step = [&](int u, auto POS, uint4& fa, uint4& fb, const uint4& na, const uint4& nb) __attribute__((always_inline)) {
         constexpr int kb = decltype(POS)::value % KB;
         // (micro-steps past u1 -- the range's length rounded up to four -- run on the last tile again: its maxima are real
         // candidates' scores once more, its pass / fail bits are dropped)
         {
         if (!(MMREC_TF_PROBE & 4)) gload(u + F_PF, fa, fb);
-        constexpr int par = decltype(POS)::value & 1;
         half8 ca[4], cb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (PFR) { ca[s] = oa[par][s]; cb[s] = ob[par][s]; continue; }
             if (MMREC_TF_PROBE & 2) { ca[s] = qf[0][s]; cb[s] = qf[1][s]; continue; }
             ca[s] = __builtin_bit_cast(half8, s_c[cur][0][i * 8 + ((h * 4 + s) ^ sw)]);
             cb[s] = __builtin_bit_cast(half8, s_c[cur][1][i * 8 + ((h * 4 + s) ^ sw)]);
@@ -458,20 +437,9 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
                 b1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb[s], qf[1][kb * 4 + s], b1, 0, 0, 0);
             }
         }
-        const int nx1 = PFR ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
-        if (PFR) {       // operands of micro-step u + 1 (its tile was written during u - 1), then tile u + 2 into the third buffer
-            const int nx2 = nx1 == 2 ? 0 : nx1 + 1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                oa[par ^ 1][s] = __builtin_bit_cast(half8, s_c[nx1][0][i * 8 + ((h * 4 + s) ^ sw)]);
-                ob[par ^ 1][s] = __builtin_bit_cast(half8, s_c[nx1][1][i * 8 + ((h * 4 + s) ^ sw)]);
-            }
-            s_c[nx2][0][slot] = na;
-            s_c[nx2][1][slot] = nb;
-        } else {         // the next tile goes to the other LDS buffer while the matrix pipe drains
-            s_c[nx1][0][slot] = na;
-            s_c[nx1][1][slot] = nb;
-        }
+        // the next tile goes to the other LDS buffer while the matrix pipe drains
+        s_c[cur ^ 1][0][slot] = na;
+        s_c[cur ^ 1][1][slot] = nb;
         // a?[r] / b?[r] = score of candidate 64 t (+ 32) + (r & 3) + 8 (r >> 2) + 4 h for query q0 + 32 f + i
         if (kb != KB - 1) {
             // (more column blocks of this stage to come)
@@ -540,7 +508,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
             }
         }
         if (!(MMREC_TF_PROBE & 16)) __syncthreads();
-        cur = nx1;
+        cur ^= 1;
         }
         if (FILTER && kb == KB - 1) {      // a stage done: its 32 bits per fragment
             if (u >= u1) w[0] = w[1] = 0u;
@@ -569,21 +537,11 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) v
     using P2 = std::integral_constant<int, 2>;
     using P3 = std::integral_constant<int, 3>;
     for (int ub = u0; ub < u1; ub += F_PF) {       // four micro-steps = four stages (KB = 1) / two stages (KB = 2)
-        if (PFR) {
-            step(ub, P0{}, ra0, rb0, ra2, rb2);
-            step(ub + 1, P1{}, ra1, rb1, ra3, rb3);
-        } else {
-            step(ub, P0{}, ra0, rb0, ra1, rb1);
-            step(ub + 1, P1{}, ra1, rb1, ra2, rb2);
-        }
+        step(ub, P0{}, ra0, rb0, ra1, rb1);
+        step(ub + 1, P1{}, ra1, rb1, ra2, rb2);
         if (KB == 1) flush((ub - u0) >> 1);
-        if (PFR) {
-            step(ub + 2, P2{}, ra2, rb2, ra0, rb0);
-            step(ub + 3, P3{}, ra3, rb3, ra1, rb1);
-        } else {
-            step(ub + 2, P2{}, ra2, rb2, ra3, rb3);
-            step(ub + 3, P3{}, ra3, rb3, ra0, rb0);
-        }
+        step(ub + 2, P2{}, ra2, rb2, ra3, rb3);
+        step(ub + 3, P3{}, ra3, rb3, ra0, rb0);
         flush(KB == 1 ? ((ub - u0) >> 1) + 1 : (ub - u0) >> 2);
     }
     static_assert(F_PF == 4 && (KB == 1 || KB == 2), "the step sequence above is written for a 4-slot ring and 1 or 2 column blocks");

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
     "current": [],                                # the tree as it is (pass 1 on every second stage from 131,072 candidates on)
-    "nopfr": ["-DMMREC_TF_PFR=0"],                # operands read from LDS at the start of their own micro-step (two LDS buffers)
+    "scinit": ["-DMMREC_TF_SCINIT=1"],            # word-list pass 2 with accumulators started at -thr
     "p1s1": ["-DMMREC_TF_P1S=1", "-DMMREC_TF_NOCLIP=1"],    # pass 1 on every stage everywhere, no clipping (the round-2 behaviour)
 }
 
