@@ -323,7 +323,7 @@ struct PassArgs {
 // KB = kd / 64 (1 or 2): a row of 128 columns is walked as two 64-wide tiles per 64-candidate stage (the conversion lays the
 // candidates out tile by tile), accumulating into the same accumulators; the per-score work runs once per stage.
 template <bool FILTER, bool SPARSE, int KB>
-__global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE) ? 3 : 2) void filter_pass_kernel(const PassArgs a) {
+__global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1) ? 3 : 2) void filter_pass_kernel(const PassArgs a) {
     __shared__ uint4 s_c[2][2][256];   // [buffer][32-row half of the tile][row * 8 + swizzled chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;

@@ -258,8 +258,8 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         eu, ei = unique_edges(self.interaction_matrix.row, self.interaction_matrix.col, ni)
         r, c, v = sym_norm_coo(eu, ei, nu, ni)
         chunks = config['dist_chunks']
-        if not chunks:      # a chunk should stay a >= ~2.5M-nnz SpMM, else launches dominate
-            chunks = int(min(4, max(1, r.shape[0] // self.world // 2_500_000)))
+        if not chunks:      # a chunk should stay a >= ~2.5M-nnz SpMM, else launches dominate; one rank has nothing to overlap
+            chunks = 1 if self.world == 1 else int(min(4, max(1, r.shape[0] // self.world // 2_500_000)))
         self.sharding = sh = BipartiteSharding.from_coo(r, nu, ni, self.world, n_chunks=chunks)
         self.nnz_per_rank = sh.nnz_per_rank(r)
         # ONE long-row plan for every block of the u-i graph, the single-GPU graph's (a function of ITS column count): padded

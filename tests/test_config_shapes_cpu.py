@@ -9,7 +9,8 @@ from tests.test_config_shapes_gpu import (  # noqa: F401  (collected here withou
     test_bm3_step_at_clothing_shape, test_freedom_step_at_sports_shape, test_score_topk_c5_block_vs_oracle,
     test_knn_graph_at_sports_item_count)
 from tests.test_config_shapes_gpu import (  # noqa: F401  (golden at full Amazon-Baby shape: small enough for the CPU stand-ins)
-    test_lattice_step_vs_reference_golden_at_baby_shape, test_mmgcn_step_vs_reference_golden_at_baby_shape)
+    test_lattice_step_vs_reference_golden_at_baby_shape, test_mmgcn_step_vs_reference_golden_at_baby_shape,
+    test_eval_rows_of_128_at_baby_shape)
 
 
 @pytest.fixture(autouse=True)

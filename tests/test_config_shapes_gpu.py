@@ -175,6 +175,33 @@ def test_freedom_step_at_sports_shape(tmp_path):
     topk_rows_match(idx, s, local_mask(mrows, mcols, rows), 50, rows)
 
 
+# ------------------------------------------------------------------------------------------------ 128-wide evaluation rows
+@pytest.mark.parametrize("name,hyper", [("VBPR", {"reg_weight": 1e-3}),
+                                        ("SELFCFED_LGN", {"n_layers": 2, "dropout": 0.1, "reg_weight": 1e-3})])
+def test_eval_rows_of_128_at_baby_shape(tmp_path, name, hyper):
+    """VBPR ranks cat(id embedding, projected feature) rows and SELFCFED_LGN its 128-wide propagated embeddings
+    (vbpr.py:100-106, selfcfed_lgn.py full_sort_predict): kd = 128 -- at Amazon-Baby shape (19,445 x 7,050) the plugin's
+    `full_sort_topk` runs the fp16 filter's two-column-block kernels (round 3; the materialised fp32 path before).  The
+    top-50 and top-100 lists of sampled users (the 64 most heavily masked ones included) against the oracle's trainer step
+    (orc.mask_topk, trainer.py:304-309) on float64-free CPU scores of the plugin's own evaluation embeddings."""
+    config, train_data, valid_data, model = build_shape(tmp_path, name, "baby", hyper)
+    model.eval()
+    with torch.no_grad():
+        u_all, i_all = model.eval_embeddings()
+    assert u_all.shape[1] == 128 and i_all.shape == (model.n_items, 128)
+    batches = list(valid_data)
+    users, mask = batches[0][0], batches[0][1]
+    mrows, mcols = mask[0].cpu().numpy(), mask[1].cpu().numpy()
+    cnt = np.bincount(mrows, minlength=users.shape[0])
+    rng = np.random.default_rng(0)
+    rows = np.unique(np.concatenate([np.argsort(-cnt)[:64], rng.choice(users.shape[0], min(1024, users.shape[0]), False)]))
+    s = orc.full_sort_scores(u_all.detach().cpu(), i_all.detach().cpu(), users.cpu()[rows])
+    for k in (50, 100):
+        idx = model.full_sort_topk(batches[0], k).cpu().numpy()
+        assert idx.shape == (users.shape[0], k)
+        topk_rows_match(idx, s, local_mask(mrows, mcols, rows), k, rows)
+
+
 # ------------------------------------------------------------------------------------------------ C4: BM3 / Clothing
 def test_bm3_step_at_clothing_shape(tmp_path, monkeypatch):
     """One BM3 training step at Amazon-Clothing shape (BASELINE config 4: n_layers 2, dropout 0.3) with the four

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
     "current": [],                                # the tree as it is (pass 1 on every second stage from 131,072 candidates on)
-    "scinit": ["-DMMREC_TF_SCINIT=1"],            # word-list pass 2 with accumulators started at -thr
+    "occ3": ["-DMMREC_TF_OCC3=1"],                # word-list pass 2 (kd = 64) at three workgroups per CU: 166 VGPRs, no spills since the prefetch fix
     "p1s1": ["-DMMREC_TF_P1S=1", "-DMMREC_TF_NOCLIP=1"],    # pass 1 on every stage everywhere, no clipping (the round-2 behaviour)
 }
 
