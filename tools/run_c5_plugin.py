@@ -102,6 +102,18 @@ def main():
             dt = time.time() - t
             log("sharded=%s: %s evaluation of %d users in %.2fs (%.0f users/s incl. metrics), recall@20 %.4f" %
                 (sharded, which, valid_data.pr_end, dt, valid_data.pr_end / dt, res["recall@20"]))
+        if os.environ.get("MMREC_C5_PROFILE_EVAL"):          # where a Trainer evaluation's host time goes
+            import cProfile
+            import io
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            trainer.evaluate(valid_data)
+            torch.cuda.synchronize()
+            pr.disable()
+            buf = io.StringIO()
+            pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(35)
+            log("cProfile of a third evaluation:\n" + buf.getvalue())
         log("sharded=%s: peak device memory %.1f GB" % (sharded, torch.cuda.max_memory_allocated() / 2 ** 30))
         del model, trainer, train_data, valid_data, data
         torch.cuda.empty_cache()
