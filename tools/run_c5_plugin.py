@@ -95,6 +95,20 @@ def main():
         losses[sharded] = [float(x) for x in per]
         log("sharded=%s: %d training steps, %.2f ms/step (loss first %.6f last %.6f)" %
             (sharded, steps, dt / steps * 1e3, losses[sharded][0], losses[sharded][-1]))
+        late = int(os.environ.get("MMREC_C5_LATE_STEPS", "0"))
+        if late:     # the row-lazy Adam replays the steps a row sat out: its cost grows until every row has been touched
+            more = []
+            for b in train_data:
+                more.append(b)
+                if len(more) == late + steps:
+                    break
+            trainer._train_epoch(more[:late], 0)
+            torch.cuda.synchronize()
+            t = time.time()
+            trainer._train_epoch(more[late:], 0)
+            torch.cuda.synchronize()
+            log("sharded=%s: after %d more steps: %.2f ms/step over %d steps" %
+                (sharded, late, (time.time() - t) / max(len(more) - late, 1) * 1e3, len(more) - late))
         for which in ("first (builds the per-batch mask CSRs, cached on the loader)", "second"):
             t = time.time()
             res = trainer.evaluate(valid_data)
@@ -102,6 +116,14 @@ def main():
             dt = time.time() - t
             log("sharded=%s: %s evaluation of %d users in %.2fs (%.0f users/s incl. metrics), recall@20 %.4f" %
                 (sharded, which, valid_data.pr_end, dt, valid_data.pr_end / dt, res["recall@20"]))
+        if os.environ.get("MMREC_C5_DIAG"):                  # survivor statistics of the top-K filter on the embeddings just ranked
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from topk_survivor_model import survivor_stats
+            ue, ie = model._cached_eval_embeddings() if hasattr(model, "_cached_eval_embeddings") else model.eval_embeddings()
+            rs = np.random.default_rng(0).choice(model.n_users, 256, replace=False)
+            deg = np.bincount(model.interaction_matrix.row, minlength=model.n_users)
+            survivor_stats(ue[torch.as_tensor(rs, device=ue.device)].float().cpu().numpy(), ie.float().cpu().numpy(), deg[rs],
+                           tag="[c5] diag: ")
         if os.environ.get("MMREC_C5_PROFILE_EVAL"):          # where a Trainer evaluation's host time goes
             import cProfile
             import io

@@ -16,6 +16,59 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from mmrec_amd import synth  # noqa: E402
 
 
+def clip_threshold(cn):
+    """tau of filter_clip_kernel: histogram of the norms over float bits >> 20, lowest bin with <= 32 rows from it upwards."""
+    bins = np.ascontiguousarray(cn, dtype=np.float32).view(np.uint32) >> 20
+    hist = np.bincount(bins, minlength=2048)
+    cum, b = 0, 2048
+    for j in range(2047, -1, -1):
+        if cum + hist[j] > 32:
+            break
+        cum, b = cum + hist[j], j
+    return (np.array([b << 20], dtype=np.uint32).view(np.float32)[0] if cum > 0 else np.inf), cum
+
+
+def survivor_stats(U, I, m_per_query, k=50, tag="", clip=True):
+    """U [nq, d] sampled query rows, I [ni, d] candidates, m_per_query masked items per query: survivors of the filter's bound
+    at pass-1 strides 1 and 2 (as main() does), with the clipping of outlying candidate rows the kernels apply from 131,072
+    candidates on."""
+    ni = I.shape[0]
+    mean = I.mean(0)
+    Ic = I - mean
+    cn = np.linalg.norm(Ic, axis=1)
+    cmax = cn.max()
+    tau, n_out = clip_threshold(cn) if clip and ni >= 131072 else (np.inf, 0)
+    out = cn >= tau
+    if n_out:
+        Ic = Ic * np.minimum(1.0, tau / np.maximum(cn, 1e-30))[:, None]
+    print("%scentred candidate norms: median %.3g  p99 %.3g  p99.99 %.3g  max %.3g; clipped rows %d at tau %.3g" % (
+        tag, np.median(cn), np.percentile(cn, 99), np.percentile(cn, 99.99), cmax, n_out, tau))
+    n_stages = (ni + 63) // 64
+    n_ranges = 16
+    spr = (-(-n_stages // n_ranges) + 3) // 4 * 4
+    cm = min(cmax, tau)
+    for S in (1, 2):
+        surv, plain, low = [], [], 0
+        for q in range(U.shape[0]):
+            s = Ic @ U[q]
+            m, qn = int(m_per_query[q]), np.linalg.norm(U[q])
+            eps = qn * (1.0e-3 * cm + 4e-6 * (cmax + np.linalg.norm(mean))) + 2.4e-7 * (qn + cm)
+            gm = np.full(32 * n_ranges, -np.inf)
+            for rg in range(n_ranges):
+                st = np.arange(rg * spr, min((rg + 1) * spr, ni // 64))[::S]
+                if len(st):
+                    gm[rg * 32:(rg + 1) * 32] = s[st[:, None] * 64 + np.arange(64)[None, :]].reshape(len(st), 2, 32).max(axis=(0, 1))
+            bound = np.sort(gm)[::-1][k + m - 1]
+            low += bound < eps
+            surv.append(int(((s >= bound - 2 * eps) | out).sum()))
+            plain.append(int((s >= bound).sum()))
+        surv, plain = np.array(surv), np.array(plain)
+        print("%sstride %d: survivors median %d p90 %d p99 %d max %d (without the 2 eps margin: median %d); > 256: %.3f  > 512: %.3f; "
+              "bound < eps (slow queue when rows are clipped): %.3f" % (
+                  tag, S, np.median(surv), np.percentile(surv, 90), np.percentile(surv, 99), surv.max(), np.median(plain),
+                  (surv > 256).mean(), (surv > 512).mean(), low / U.shape[0]))
+
+
 def main(shape):
     nu, ni, eu, ei = synth.shaped_edges(shape, seed=0)
     r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
