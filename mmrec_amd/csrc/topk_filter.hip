@@ -72,6 +72,8 @@ constexpr int F_SPARSE_NC = 32768;   // from this many candidates on pass 2 appe
 constexpr int F_WCAP = 256;          // ... of this many (word index, word) entries per query (each holds >= 1 survivor);
 constexpr int F_WCAP2 = 512;         // ... twice as many where pass 1 subsamples (filter_plan): ~2 x the survivors
 constexpr int F_P1S2_NC = 131072;    // from this many candidates on pass 1 walks every second stage
+constexpr int F_POOL_CAP = 1 << 20;  // entries of the call's overflow pool: words of queries whose own list is full (16 MiB)
+constexpr int F_OVER_IDS = 4096;     // survivors of ONE overflowing query the overflow kernel ranks (16 KiB of LDS)
 constexpr int F_PF = 4;        // 64-candidate stages in flight per workgroup (register ring)
 constexpr int F_MASK_LDS = 512; // mask entries per query staged in LDS by the final kernel (>= F_MAXR * 32)
 
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int row = t / W, ch = t % W;   // grid covers n_pad rows exactly (n_pad % 64 == 0)
     if (!CAND) {   // the call's counters, zeroed on the way (one int, and one int per real row)
-        if (t == 0 && zero_one) *zero_one = 0;
+        if (t < 3 && zero_one) zero_one[t] = 0;      // slow-queue length, overflow-queue length, pool entries
         if (ch == 0 && row < n && zero_rows) zero_rows[row] = 0;
     }
     float x[8];
@@ -291,7 +293,9 @@ struct PassArgs {
     const float* thr;     // pass 2 in:  [nq]
     unsigned long long* bits;   // pass 2 out: [nq][ranges][2][stages_per_range / 2] pass / fail bits
     int* wcnt;            // pass 2 out, SPARSE: [nq] appended words (zeroed by the launcher)
-    uint4* wlist;         // pass 2 out, SPARSE: [nq][wcap] (word index in the row above, 0, word lo, word hi)
+    uint4* wlist;         // pass 2 out, SPARSE: [nq][wcap] (word index in the row above, query, word lo, word hi)
+    uint4* pool;          // ... words that do not fit a query's list: [F_POOL_CAP], one counter (counters[2])
+    int* counters;        // {slow-queue length, overflow-queue length, pool entries}
 };
 
 // The MFMAs of a stage are issued back to back (four independent accumulator chains, alternating): on gfx950 ANY
@@ -374,9 +378,15 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            if (ps[f] >= 0 && ps[f] < a.wcap)
-                a.wlist[(size_t)(q0 + f * 32 + i) * a.wcap + ps[f]] =
-                    make_uint4(pw[f], 0u, (unsigned)pb[f], (unsigned)(pb[f] >> 32));
+            if (ps[f] >= 0) {
+                const uint4 ent = make_uint4(pw[f], (unsigned)(q0 + f * 32 + i), (unsigned)pb[f], (unsigned)(pb[f] >> 32));
+                if (ps[f] < a.wcap) {
+                    a.wlist[(size_t)(q0 + f * 32 + i) * a.wcap + ps[f]] = ent;
+                } else {      // the query's list is full (heavy users, closely packed scores, ties): the call's shared pool
+                    const int slot = atomicAdd(a.counters + 2, 1);
+                    if (slot < F_POOL_CAP) a.pool[slot] = ent;
+                }
+            }
             ps[f] = -1;
         }
     };
@@ -710,16 +720,19 @@ __device__ __forceinline__ void sort_best_k(const unsigned long long* list, int 
 // (64 packed entries) instead of the outputs -- large candidate sets are split over several workgroups per query and
 // merged by filter_slow_merge_kernel (one workgroup streaming 500K candidates for ONE flagged query took 5 ms, as long
 // as the whole 20,000-query block of the fast path).
-template <int KB>
+// LISTED: the candidates are the n_listed ids of `listed` (LDS; ARBITRARY order: the survivors of an overflowing query,
+// filter_overflow_kernel) instead of the steps [st0, st1) of all candidates; the running threshold is then the k-th best
+// (score, id) PAIR, since a later tie may carry the smaller id.
+template <int KB, bool LISTED = false>
 __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
                                           const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
                                           int q, unsigned long long (*lists)[F_CAPQ], unsigned long long* merged,
                                           int32_t* mask_lds, int lane, int wave, int64_t* __restrict__ out_idx,
                                           float* __restrict__ out_val, int st0, int st1,
-                                          unsigned long long* __restrict__ part) {
+                                          unsigned long long* __restrict__ part, const int* listed = nullptr, int n_listed = 0) {
     unsigned long long* list = lists[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int steps = st1;
+    const int steps = LISTED ? (n_listed + 63) / 64 : st1;
     q = __builtin_amdgcn_readfirstlane(q);
     const float4* q4 = reinterpret_cast<const float4*>(Q) + (size_t)q * (16 * KB);   // wave-uniform: scalar loads
     // the query's sorted mask list: binary-searched per candidate, from LDS when it fits (heavy users are what this
@@ -733,13 +746,15 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
     }
     __syncthreads();
     float teff = -INFINITY;
+    Cand kth = Cand{-INFINITY, INT_MAX};      // LISTED: the k-th best pair so far
     int cnt = 0;
     for (int it = st0 + wave;; it += F_SLOW_WAVES) {
         const bool last = it >= steps;
         if (!last) {
-            const int c = it * 64 + lane;
+            const int e_l = it * 64 + lane;
+            const int c = LISTED ? (e_l < n_listed ? listed[e_l] : INT_MAX) : e_l;
             float v = -INFINITY;
-            if (c < nc) {
+            if (c >= 0 && c < nc) {
                 v = exact_score<KB>(q4, reinterpret_cast<const float4*>(C) + (size_t)c * (16 * KB));
                 int lo = 0, hi = m;
                 while (lo < hi) {
@@ -748,7 +763,7 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
                 }
                 if (lo < m && ml[lo] == c) v = -1e10f;
             }
-            const bool pass = v > teff;
+            const bool pass = LISTED ? (c >= 0 && c < nc && cand_before(Cand{v, c}, kth)) : v > teff;
             const unsigned long long b = __ballot(pass);
             if (pass) list[cnt + __popcll(b & lt)] = pack_cand(v, c);
             cnt += __popcll(b);
@@ -769,7 +784,10 @@ __device__ __forceinline__ void slow_topk(const float* __restrict__ Q, const flo
         if (64 + lane < keep) list[64 + lane] = pack_cand(y1.v, y1.i);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         cnt = keep;
-        if (n >= k) teff = fmaxf(teff, k <= 64 ? __shfl(y0.v, k - 1, 64) : __shfl(y1.v, k - 65, 64));
+        if (n >= k) {
+            teff = fmaxf(teff, k <= 64 ? __shfl(y0.v, k - 1, 64) : __shfl(y1.v, k - 65, 64));
+            if (LISTED) kth = Cand{teff, k <= 64 ? __shfl(y0.i, k - 1, 64) : __shfl(y1.i, k - 65, 64)};   // (the kept list holds the old top-k)
+        }
     }
     __syncthreads();
     if (wave == 0) {
@@ -802,7 +820,9 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     const unsigned long long* __restrict__ bits, const int* __restrict__ wcnt, const uint4* __restrict__ wlist,
     int n_ranges, int tiles_per_range, const int* __restrict__ flag,
     int* __restrict__ flist, int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val,
-    const int* __restrict__ outl) {   // outl: nullptr, or {count, ids ...} of the clipped candidate rows (always rescored)
+    const int* __restrict__ outl,     // outl: nullptr, or {count, ids ...} of the clipped candidate rows (always rescored)
+    int* __restrict__ olist) {        // SPARSE: queue of the queries whose survivors do not fit CAP (filter_overflow_kernel);
+                                      // its length is n_flagged[1]
     __shared__ unsigned long long s_l[4][CAP];   // (score, id) of the unmasked survivors
     __shared__ int s_ids[4][CAP];
     __shared__ int s_mask[4][F_MASK_LDS];
@@ -855,6 +875,9 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
         return;
     }
     bool bad = fl != 0 || m > F_MASK_LDS || n_app > CAP;
+    // more survivors than slots (the list itself, or the ids its words decode to): the overflow queue ranks them exactly
+    // from the list + the call's pool -- not the slow queue's scan of ALL candidates
+    bool over = SPARSE && olist && fl == 0 && n_app > CAP;
     if (!bad) {
         // A: decode the pass / fail bits of pass 2 into candidate ids; stage the query's sorted mask list
         for (int e = lane; e < m; e += 64) s_mask[wave][e] = mask_col[m_lo + e];
@@ -897,6 +920,7 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             }
             if (n != n0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+        if (n > CAP && SPARSE && olist) over = true;
         if (n > CAP || n < k) bad = true;
 #pragma unroll
         for (int u = 0; u < CAP / 64; ++u) c[u] = (!bad && lane + 64 * u < n) ? (int)s_l[wave][lane + 64 * u] : -1;
@@ -955,7 +979,11 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             }
         }
     }
-    if (bad && lane == 0) flist[atomicAdd(n_flagged, 1)] = q;   // served by filter_slow_kernel
+    if (over) {
+        if (lane == 0) olist[atomicAdd(n_flagged + 1, 1)] = q;       // served by filter_overflow_kernel
+    } else if (bad && lane == 0) {
+        flist[atomicAdd(n_flagged, 1)] = q;                          // served by filter_slow_kernel
+    }
 }
 
 // The queue of the final kernel, served by persistent workgroups (inlining slow_topk into the final kernel doubled
@@ -983,6 +1011,72 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
         const int st0 = (int)((long long)steps * sp / S), st1 = (int)((long long)steps * (sp + 1) / S);
         slow_topk<KB>(Q, C, nc, k, mask_rowptr, mask_col, flist[j], s_l, s_m, s_mask, lane, wave, out_idx, out_val, st0, st1,
                   S > 1 ? parts + (size_t)w * 128 : nullptr);
+    }
+}
+
+// The overflow queue of the final kernel (SPARSE), served by persistent workgroups: a query with more surviving words than
+// its list holds (heavy users: ~2 (k + m) survivors; queries whose scores are packed within 2 eps of the bound -- 0.1 % of the
+// users of a TRAINED config-5 model, which cost half the evaluation's time in the slow queue's scan of all 500K candidates)
+// is ranked exactly from what pass 2 found: its list + its words in the call's pool (+ the clipped rows), decoded into an
+// id list in LDS and streamed through slow_topk.  A pool or id list that overflows in turn sends the query on to the slow
+// queue (this kernel runs before filter_slow_kernel).
+template <int KB>
+__global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_overflow_kernel(
+    const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
+    const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col, const int* __restrict__ olist,
+    int* __restrict__ counters, const int* __restrict__ wcnt, const uint4* __restrict__ wlist, int wcap,
+    const uint4* __restrict__ pool, int tiles_per_range, const int* __restrict__ outl, int* __restrict__ flist,
+    int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    __shared__ unsigned long long s_l[F_SLOW_WAVES][F_CAPQ];
+    __shared__ unsigned long long s_m[F_SLOW_WAVES * 128];
+    __shared__ int32_t s_mask[F_SLOW_MASK_LDS];
+    __shared__ int s_ids[F_OVER_IDS];
+    __shared__ int s_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_over = counters[1];
+    const int n_pool = counters[2];
+    const int gpr = tiles_per_range >> 2;
+    for (int j = blockIdx.x; j < n_over; j += gridDim.x) {       // uniform per workgroup
+        const int q = olist[j];
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        auto decode = [&](const uint4 t) {     // the word's set bits -> candidate ids (the final kernel's arithmetic)
+            const int wi = (int)t.x, rg = wi / gpr, g = wi - rg * gpr;
+            const int cbase = ((rg >> 1) * tiles_per_range + 4 * g) * 32 + 4 * (rg & 1);
+            unsigned long long x = (unsigned long long)t.z | ((unsigned long long)t.w << 32);
+            while (x != 0ull) {
+                const int pz = __clzll((long long)x);
+                x &= ~(0x8000000000000000ull >> pz);
+                const int r = pz & 15, dst = atomicAdd(&s_n, 1);
+                if (dst < F_OVER_IDS) s_ids[dst] = cbase + (pz >> 4) * 32 + (r & 3) + 8 * (r >> 2);
+            }
+        };
+        const int n_own = min(wcnt[q], wcap);
+        for (int e = threadIdx.x; e < n_own; e += 64 * F_SLOW_WAVES) decode(wlist[(size_t)q * wcap + e]);
+        if (n_pool <= F_POOL_CAP)
+            for (int e = threadIdx.x; e < n_pool; e += 64 * F_SLOW_WAVES) {
+                const uint4 t = pool[e];
+                if ((int)t.y == q) decode(t);
+            }
+        __syncthreads();
+        int n_ids = s_n;
+        const int n_out = outl ? outl[0] : 0;
+        __syncthreads();
+        if (n_pool > F_POOL_CAP || n_ids + n_out > F_OVER_IDS) {      // not everything pass 2 found is here: the exact slow queue
+            if (threadIdx.x == 0) flist[atomicAdd(counters, 1)] = q;
+            continue;
+        }
+        // the clipped candidate rows, unless pass 2 let them through (a wave per row, round robin)
+        for (int o = wave; o < n_out; o += F_SLOW_WAVES) {
+            const int id = outl[1 + o];
+            bool has = false;
+            for (int e = lane; e < n_ids; e += 64) has |= s_ids[e] == id;
+            if (__ballot(has) == 0ull && lane == 0) s_ids[atomicAdd(&s_n, 1)] = id;
+        }
+        __syncthreads();
+        n_ids = s_n;
+        slow_topk<KB, true>(Q, C, nc, k, mask_rowptr, mask_col, q, s_l, s_m, s_mask, lane, wave, out_idx, out_val, 0, 0, nullptr,
+                            s_ids, n_ids);
     }
 }
 
@@ -1106,7 +1200,7 @@ size_t topk64_filter_workspace_bytes(int nq, int nc, int kd, int k) {
     const FilterPlan p = filter_plan(nq, nc);
     return al256f((size_t)p.nq_pad * 2 * kd) + topk64_filter_prepared_bytes(nc, kd) + al256f((size_t)p.nq_pad * 4) + 256 +
            al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f(p.bits_bytes) +
-           al256f((size_t)F_SLOW_PARTS * 128 * 8);
+           al256f((size_t)F_SLOW_PARTS * 128 * 8) + (p.sparse ? al256f((size_t)nq * 4) + (size_t)F_POOL_CAP * 16 : 0);
 }
 
 namespace {
@@ -1130,6 +1224,9 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     uint4* wlist = reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4));   //         [nq][wcap] entries
     ws += al256f(p.bits_bytes);
     unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][128]
+    ws += al256f((size_t)F_SLOW_PARTS * 128 * 8);
+    int* olist = p.sparse ? reinterpret_cast<int*>(ws) : nullptr;           // sparse: overflow queue, then the pool
+    uint4* pool = p.sparse ? reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4)) : nullptr;
     if (!prepared) {
         const int rc = topk64_filter_prepare(C, nc, kd, own, s);
         if (rc != 0) return rc;
@@ -1142,7 +1239,7 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     // the query-side conversion also zeroes the call's counters (slow-queue length, word-list lengths): no memset launches
     hipLaunchKernelGGL((filter_convert_kernel<false, 8 * KB>), dim3(p.nq_pad * 8 * KB / 256), dim3(256), 0, s, Q, nq, p.nq_pad,
                        stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
-    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist};
+    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist, pool, n_flagged};
     const dim3 grid(p.qblocks, p.R);
     hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
@@ -1154,13 +1251,16 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
     if (p.sparse && p.wcap == F_WCAP2)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP2>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist);
     else if (p.sparse)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist);
     else
         hipLaunchKernelGGL((filter_final_kernel<false, KB, F_CAPQ>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist);
+    if (p.sparse)
+        hipLaunchKernelGGL(filter_overflow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col,
+                           olist, n_flagged, wcnt, wlist, p.wcap, pool, 2 * p.spr, outl, flist, out_idx, out_val);
     const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
     hipLaunchKernelGGL(filter_slow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
                        n_flagged, out_idx, out_val, want, parts);
