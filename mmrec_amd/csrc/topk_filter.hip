@@ -318,9 +318,6 @@ struct PassArgs {
 #ifndef MMREC_TF_NOCLIP    // probe: no clipping of outlying candidate rows
 #define MMREC_TF_NOCLIP 0
 #endif
-#ifndef MMREC_TF_SCINIT    // probe: the word-list pass 2 starts its accumulators at -thr too
-#define MMREC_TF_SCINIT 0
-#endif
 #ifndef MMREC_TF_OCC3      // probe: three workgroups per CU for the word-list pass 2 (168 VGPRs: 12 spilled)
 #define MMREC_TF_OCC3 0
 #endif
@@ -351,9 +348,10 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
     // query fragments: lane (i, h) holds B[k = 32 h + 8 s + j][n = i], i.e. chunk 4 h + s of column block kb of its query row
     half8 qf[2][4 * KB];
     // C operand of a chain's first MFMA: 0 (pass 1) / -thr of the lane's query (pass 2: acc = score - thr, the pass / fail
-    // bit is the accumulator's sign).  The word-list variant and the 128-wide rows have no 32 registers to spare for it (256
-    // per wave at two workgroups per CU): they keep thr in one register per fragment and subtract per score.
-    constexpr bool CINIT = FILTER && (!SPARSE || MMREC_TF_SCINIT) && KB == 1;
+    // bit is the accumulator's sign).  The 128-wide rows have no 32 registers to spare for it (256 per wave at two workgroups
+    // per CU); the word-list variant has since the prefetch fix (206 VGPRs with it) but measured 0-4 % slower with it than with
+    // its quarter-stage skip: both keep thr in one register per fragment and subtract per score.
+    constexpr bool CINIT = FILTER && !SPARSE && KB == 1;
     acc16 cinit[2];
     float thr[2];
     unsigned long long* brow[2];
@@ -371,7 +369,6 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
     }
     // SPARSE: the append in flight per fragment (slot < 0: none)
     int ps[2] = {-1, -1};
-    int pcnt[2] = {0, 0};
     unsigned pw[2] = {0u, 0u};
     unsigned long long pb[2] = {0ull, 0ull};
     const unsigned wbase = (blockIdx.y * 2 + h) * (a.stages_per_range >> 1);
@@ -465,7 +462,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
             // the accumulators started at -thr: acc = score - thr, FAIL bit = its sign; w = (w << 1) | bit is ONE
             // v_alignbit_b32 per score (no subtraction); the word is inverted once per 32 scores
             w[0] = w[1] = 0u;
-            if (CINIT && !SPARSE) {
+            if (CINIT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     w[0] = __builtin_amdgcn_alignbit(w[0], __float_as_uint(a0[r]), 31);
@@ -494,15 +491,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
                     m = __builtin_fmaxf(__builtin_fmaxf(m, x[r0 + 3]), x[r0 + 4]);
                     m = __builtin_fmaxf(__builtin_fmaxf(m, x[r0 + 5]), x[r0 + 6]);
                     m = __builtin_fmaxf(m, x[r0 + 7]);
-                    if (CINIT) {            // (probe) x = score - thr: FAIL bit = its sign
-                        if (__ballot(!(m < 0.f)) != 0ull) {
-#pragma unroll
-                            for (int r = r0; r < r0 + 8; ++r) wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(x[r]), 31);
-                            wd ^= 0xffu;
-                        } else {
-                            wd <<= 8;
-                        }
-                    } else if (__ballot(m > t) != 0ull) {
+                    if (__ballot(m > t) != 0ull) {
 #pragma unroll
                         for (int r = r0; r < r0 + 8; ++r) wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(t - x[r]), 31);
                     } else {
@@ -536,7 +525,7 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
                 if (bw[f] != 0ull && q0 + f * 32 + i < a.nq) {
-                    ps[f] = (MMREC_TF_PROBE & 64) ? pcnt[f]++ : atomicAdd(a.wcnt + q0 + f * 32 + i, 1);   // (probe 64: timing only, WRONG lists)
+                    ps[f] = atomicAdd(a.wcnt + q0 + f * 32 + i, 1);
                     pw[f] = wbase + (unsigned)g;
                     pb[f] = bw[f];
                 }
@@ -556,7 +545,6 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
     }
     static_assert(F_PF == 4 && (KB == 1 || KB == 2), "the step sequence above is written for a 4-slot ring and 1 or 2 column blocks");
     if (FILTER && SPARSE) commit();
-    if (FILTER && SPARSE && (MMREC_TF_PROBE & 64)) { atomicAdd(a.wcnt + q0 + i, pcnt[0]); atomicAdd(a.wcnt + q0 + 32 + i, pcnt[1]); }
     }
     if (!FILTER) {
 #pragma unroll
