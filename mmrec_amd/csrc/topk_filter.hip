@@ -72,7 +72,8 @@ constexpr int F_SPARSE_NC = 32768;   // from this many candidates on pass 2 appe
 constexpr int F_WCAP = 256;          // ... of this many (word index, word) entries per query (each holds >= 1 survivor);
 constexpr int F_WCAP2 = 512;         // ... twice as many where pass 1 subsamples (filter_plan): ~2 x the survivors
 constexpr int F_P1S2_NC = 131072;    // from this many candidates on pass 1 walks every second stage
-constexpr int F_POOL_CAP = 1 << 20;  // entries of the call's overflow pool: words of queries whose own list is full (16 MiB)
+constexpr int F_WLIST_X = 2;         // a query's list holds F_WLIST_X x as many words as the final kernel has survivor slots: the
+                                     // overflow kernel ranks the queries in between (heavy users, closely packed scores, ties)
 constexpr int F_OVER_IDS = 4096;     // survivors of ONE overflowing query the overflow kernel ranks (16 KiB of LDS)
 constexpr int F_PF = 4;        // 64-candidate stages in flight per workgroup (register ring)
 constexpr int F_MASK_LDS = 512; // mask entries per query staged in LDS by the final kernel (>= F_MAXR * 32)
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void filter_convert_kernel(const float* __rest
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int row = t / W, ch = t % W;   // grid covers n_pad rows exactly (n_pad % 64 == 0)
     if (!CAND) {   // the call's counters, zeroed on the way (one int, and one int per real row)
-        if (t < 3 && zero_one) zero_one[t] = 0;      // slow-queue length, overflow-queue length, pool entries
+        if (t < 2 && zero_one) zero_one[t] = 0;      // slow-queue length, overflow-queue length
         if (ch == 0 && row < n && zero_rows) zero_rows[row] = 0;
     }
     float x[8];
@@ -288,14 +289,12 @@ struct PassArgs {
     const uint4* Cs;      // [n_stages * 64][8]
     int nq, nc, n_stages, stages_per_range, n_groups;
     int p1_stride;        // pass 1 looks at every p1_stride-th stage of a range only (see filter_plan)
-    int wcap;             // SPARSE: entries per query in wlist (F_WCAP / F_WCAP2)
+    int wcap;             // SPARSE: entries per query in wlist (F_WLIST_X x the final kernel's survivor slots)
     unsigned* gkeys;      // pass 1 out: [nq][n_groups] monotone keys of the group maxima
     const float* thr;     // pass 2 in:  [nq]
     unsigned long long* bits;   // pass 2 out: [nq][ranges][2][stages_per_range / 2] pass / fail bits
     int* wcnt;            // pass 2 out, SPARSE: [nq] appended words (zeroed by the launcher)
-    uint4* wlist;         // pass 2 out, SPARSE: [nq][wcap] (word index in the row above, query, word lo, word hi)
-    uint4* pool;          // ... words that do not fit a query's list: [F_POOL_CAP], one counter (counters[2])
-    int* counters;        // {slow-queue length, overflow-queue length, pool entries}
+    uint4* wlist;         // pass 2 out, SPARSE: [nq][wcap] (word index in the row above, 0, word lo, word hi)
 };
 
 // The MFMAs of a stage are issued back to back (four independent accumulator chains, alternating): on gfx950 ANY
@@ -375,15 +374,9 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            if (ps[f] >= 0) {
-                const uint4 ent = make_uint4(pw[f], (unsigned)(q0 + f * 32 + i), (unsigned)pb[f], (unsigned)(pb[f] >> 32));
-                if (ps[f] < a.wcap) {
-                    a.wlist[(size_t)(q0 + f * 32 + i) * a.wcap + ps[f]] = ent;
-                } else {      // the query's list is full (heavy users, closely packed scores, ties): the call's shared pool
-                    const int slot = atomicAdd(a.counters + 2, 1);
-                    if (slot < F_POOL_CAP) a.pool[slot] = ent;
-                }
-            }
+            if (ps[f] >= 0 && ps[f] < a.wcap)
+                a.wlist[(size_t)(q0 + f * 32 + i) * a.wcap + ps[f]] =
+                    make_uint4(pw[f], 0u, (unsigned)pb[f], (unsigned)(pb[f] >> 32));
             ps[f] = -1;
         }
     };
@@ -809,8 +802,9 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     int n_ranges, int tiles_per_range, const int* __restrict__ flag,
     int* __restrict__ flist, int* __restrict__ n_flagged, int64_t* __restrict__ out_idx, float* __restrict__ out_val,
     const int* __restrict__ outl,     // outl: nullptr, or {count, ids ...} of the clipped candidate rows (always rescored)
-    int* __restrict__ olist) {        // SPARSE: queue of the queries whose survivors do not fit CAP (filter_overflow_kernel);
+    int* __restrict__ olist,          // SPARSE: queue of the queries whose survivors do not fit CAP (filter_overflow_kernel);
                                       // its length is n_flagged[1]
+    int wcap) {                       // SPARSE: entries per query in wlist (>= CAP)
     __shared__ unsigned long long s_l[4][CAP];   // (score, id) of the unmasked survivors
     __shared__ int s_ids[4][CAP];
     __shared__ int s_mask[4][F_MASK_LDS];
@@ -824,7 +818,7 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     const int n_app = SPARSE ? wcnt[q] : 0;
     const int n_words = SPARSE ? min(n_app, CAP) : n_ranges * 2 * gpr;
     const unsigned long long* row = SPARSE ? nullptr : bits + (size_t)q * n_words;
-    const uint4* ents = SPARSE ? wlist + (size_t)q * CAP : nullptr;
+    const uint4* ents = SPARSE ? wlist + (size_t)q * wcap : nullptr;
     int wi_next = lane;       // index of the word `x_next` (SPARSE: read from the entry)
     auto word = [&](int e, int& wi) -> unsigned long long {
         if (SPARSE) {
@@ -864,7 +858,7 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     }
     bool bad = fl != 0 || m > F_MASK_LDS || n_app > CAP;
     // more survivors than slots (the list itself, or the ids its words decode to): the overflow queue ranks them exactly
-    // from the list + the call's pool -- not the slow queue's scan of ALL candidates
+    // from its (longer) list -- not by the slow queue's scan of ALL candidates
     bool over = SPARSE && olist && fl == 0 && n_app > CAP;
     if (!bad) {
         // A: decode the pass / fail bits of pass 2 into candidate ids; stage the query's sorted mask list
@@ -1005,15 +999,15 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_slow_kernel(
 // The overflow queue of the final kernel (SPARSE), served by persistent workgroups: a query with more surviving words than
 // its list holds (heavy users: ~2 (k + m) survivors; queries whose scores are packed within 2 eps of the bound -- 0.1 % of the
 // users of a TRAINED config-5 model, which cost half the evaluation's time in the slow queue's scan of all 500K candidates)
-// is ranked exactly from what pass 2 found: its list + its words in the call's pool (+ the clipped rows), decoded into an
-// id list in LDS and streamed through slow_topk.  A pool or id list that overflows in turn sends the query on to the slow
+// is ranked exactly from what pass 2 found: its list of up to F_WLIST_X x that many words (+ the clipped rows), decoded into
+// an id list in LDS and streamed through slow_topk.  A list or id list that overflows in turn sends the query on to the slow
 // queue (this kernel runs before filter_slow_kernel).
 template <int KB>
 __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_overflow_kernel(
     const float* __restrict__ Q, const float* __restrict__ C, int nc, int k,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col, const int* __restrict__ olist,
     int* __restrict__ counters, const int* __restrict__ wcnt, const uint4* __restrict__ wlist, int wcap,
-    const uint4* __restrict__ pool, int tiles_per_range, const int* __restrict__ outl, int* __restrict__ flist,
+    int tiles_per_range, const int* __restrict__ outl, int* __restrict__ flist,
     int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
     __shared__ unsigned long long s_l[F_SLOW_WAVES][F_CAPQ];
     __shared__ unsigned long long s_m[F_SLOW_WAVES * 128];
@@ -1022,7 +1016,6 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_overflow_kernel(
     __shared__ int s_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_over = counters[1];
-    const int n_pool = counters[2];
     const int gpr = tiles_per_range >> 2;
     for (int j = blockIdx.x; j < n_over; j += gridDim.x) {       // uniform per workgroup
         const int q = olist[j];
@@ -1039,18 +1032,13 @@ __global__ __launch_bounds__(64 * F_SLOW_WAVES) void filter_overflow_kernel(
                 if (dst < F_OVER_IDS) s_ids[dst] = cbase + (pz >> 4) * 32 + (r & 3) + 8 * (r >> 2);
             }
         };
-        const int n_own = min(wcnt[q], wcap);
-        for (int e = threadIdx.x; e < n_own; e += 64 * F_SLOW_WAVES) decode(wlist[(size_t)q * wcap + e]);
-        if (n_pool <= F_POOL_CAP)
-            for (int e = threadIdx.x; e < n_pool; e += 64 * F_SLOW_WAVES) {
-                const uint4 t = pool[e];
-                if ((int)t.y == q) decode(t);
-            }
+        const int n_app = wcnt[q];
+        for (int e = threadIdx.x; e < min(n_app, wcap); e += 64 * F_SLOW_WAVES) decode(wlist[(size_t)q * wcap + e]);
         __syncthreads();
         int n_ids = s_n;
         const int n_out = outl ? outl[0] : 0;
         __syncthreads();
-        if (n_pool > F_POOL_CAP || n_ids + n_out > F_OVER_IDS) {      // not everything pass 2 found is here: the exact slow queue
+        if (n_app > wcap || n_ids + n_out > F_OVER_IDS) {             // not everything pass 2 found is here: the exact slow queue
             if (threadIdx.x == 0) flist[atomicAdd(counters, 1)] = q;
             continue;
         }
@@ -1131,7 +1119,7 @@ inline FilterPlan filter_plan(int nq, int nc) {
     // r03_topk_pass1_stride_ab.log, r03_bench_line_p1s2.json).  Small candidate sets keep stride 1: their passes are short and
     // heavy users (k + m near the slot count) are relatively more frequent in real data.
     p.p1_stride = MMREC_TF_P1S > 0 ? MMREC_TF_P1S : (p.sparse && nc >= F_P1S2_NC ? 2 : 1);
-    p.wcap = p.p1_stride >= 2 ? F_WCAP2 : F_WCAP;
+    p.wcap = F_WLIST_X * (p.p1_stride >= 2 ? F_WCAP2 : F_WCAP);      // list entries; the final kernel has F_WCAP(2) slots
     p.bits_bytes = p.sparse ? ((((size_t)nq * 4 + 255) & ~(size_t)255) + (size_t)nq * p.wcap * 16)
                             : (size_t)nq * p.R * p.spr * 8;
     return p;
@@ -1188,7 +1176,7 @@ size_t topk64_filter_workspace_bytes(int nq, int nc, int kd, int k) {
     const FilterPlan p = filter_plan(nq, nc);
     return al256f((size_t)p.nq_pad * 2 * kd) + topk64_filter_prepared_bytes(nc, kd) + al256f((size_t)p.nq_pad * 4) + 256 +
            al256f((size_t)nq * p.n_groups * 4) + 3 * al256f((size_t)nq * 4) + al256f(p.bits_bytes) +
-           al256f((size_t)F_SLOW_PARTS * 128 * 8) + (p.sparse ? al256f((size_t)nq * 4) + (size_t)F_POOL_CAP * 16 : 0);
+           al256f((size_t)F_SLOW_PARTS * 128 * 8) + (p.sparse ? al256f((size_t)nq * 4) : 0);
 }
 
 namespace {
@@ -1213,8 +1201,7 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     ws += al256f(p.bits_bytes);
     unsigned long long* parts = reinterpret_cast<unsigned long long*>(ws);  // [F_SLOW_PARTS][128]
     ws += al256f((size_t)F_SLOW_PARTS * 128 * 8);
-    int* olist = p.sparse ? reinterpret_cast<int*>(ws) : nullptr;           // sparse: overflow queue, then the pool
-    uint4* pool = p.sparse ? reinterpret_cast<uint4*>(ws + al256f((size_t)nq * 4)) : nullptr;
+    int* olist = p.sparse ? reinterpret_cast<int*>(ws) : nullptr;           // sparse: overflow queue
     if (!prepared) {
         const int rc = topk64_filter_prepare(C, nc, kd, own, s);
         if (rc != 0) return rc;
@@ -1227,7 +1214,7 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     // the query-side conversion also zeroes the call's counters (slow-queue length, word-list lengths): no memset launches
     hipLaunchKernelGGL((filter_convert_kernel<false, 8 * KB>), dim3(p.nq_pad * 8 * KB / 256), dim3(256), 0, s, Q, nq, p.nq_pad,
                        stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
-    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist, pool, n_flagged};
+    PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist};
     const dim3 grid(p.qblocks, p.R);
     hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
@@ -1237,18 +1224,18 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     else
         hipLaunchKernelGGL((filter_pass_kernel<true, false, KB>), grid, dim3(256), 0, s, a);
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
-    if (p.sparse && p.wcap == F_WCAP2)
+    if (p.sparse && p.p1_stride >= 2)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP2>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap);
     else if (p.sparse)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap);
     else
         hipLaunchKernelGGL((filter_final_kernel<false, KB, F_CAPQ>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap);
     if (p.sparse)
         hipLaunchKernelGGL(filter_overflow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col,
-                           olist, n_flagged, wcnt, wlist, p.wcap, pool, 2 * p.spr, outl, flist, out_idx, out_val);
+                           olist, n_flagged, wcnt, wlist, p.wcap, 2 * p.spr, outl, flist, out_idx, out_val);
     const int want = nc >= F_SLOW_SPLIT_NC ? 16 : 1;
     hipLaunchKernelGGL(filter_slow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col, flist,
                        n_flagged, out_idx, out_val, want, parts);
