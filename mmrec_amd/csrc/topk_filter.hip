@@ -69,7 +69,8 @@ constexpr int F_SLOW_PARTS = 4096;      // (query, split) partial top-k lists of
 constexpr int F_SLOW_SPLIT_NC = 65536;  // from this many candidates on a flagged query is split over 16 workgroups
 constexpr int F_MIN_NC = 4096;    // below: the materialised path is as fast (fixed launch costs)
 constexpr int F_SPARSE_NC = 32768;   // from this many candidates on pass 2 appends its NON-ZERO 64-bit words to a list
-constexpr int F_WCAP = 256;          // ... of this many (word index, word) entries per query (each holds >= 1 survivor);
+constexpr int F_WCAP = 256;          // ... (word index, word) entries, each >= 1 survivor; the final kernel ranks queries of up to
+                                     // this many words (and survivors),
 constexpr int F_WCAP2 = 512;         // ... twice as many where pass 1 subsamples (filter_plan): ~2 x the survivors
 constexpr int F_P1S2_NC = 131072;    // from this many candidates on pass 1 walks every second stage
 constexpr int F_WLIST_X = 2;         // a query's list holds F_WLIST_X x as many words as the final kernel has survivor slots: the
