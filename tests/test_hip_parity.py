@@ -709,7 +709,7 @@ def test_topk_filter_path_edge_cases(ops, dev, monkeypatch):
     Qh = (rng.standard_normal((nq, 64)) * 0.2).astype(np.float32)
     for r, e in enumerate((-20, -24, -28, -30, -34, -40, -60, -100)):
         Qh[r] *= np.float32(2.0) ** e
-    Qh[20] = 0.0                                    # all scores tie at 0: slow queue, lowest ids
+    Qh[20] = 0.0                                    # all scores tie at 0: the k lowest unmasked ids (final kernel's shortcut)
     Qh[21] *= np.float32(1e25)
     Qh[22, 1:] *= np.float32(2.0) ** -30            # one dominant element
     Ch = (rng.standard_normal((nc, 64)) * 0.2 + 0.5).astype(np.float32)     # common component: exercises the centring
@@ -767,7 +767,7 @@ def test_topk_filter_word_lists(ops, dev, nq, nc):
     counters) instead of writing rows of nc / 8 bytes per query, and the final kernel decodes the lists (arbitrary order:
     the outputs stay deterministic through the final sort).  Exact boundary size, ragged last stage / tile, query
     counts that are not multiples of 256, realistic masks, one query whose candidates tie massively (> 256 non-zero
-    words: list overflow -> slow queue), one heavy user; checked against the oracle; two calls give identical results."""
+    words: more than the final kernel's slots -> overflow queue), one heavy user; checked against the oracle; two calls give identical results."""
     rng = np.random.default_rng(nq + nc)
     k = 50
     Q = rng.standard_normal((nq, 64)).astype(np.float32) * 0.2
@@ -794,7 +794,7 @@ def test_topk_filter_subsampled_pass1(ops, dev, nq, nc, k, kd):
     the (k + m)-th best from below), so ~2 (k + m) candidates survive into 512-entry word lists, and the <= 32 candidate rows
     of outlying norm are stored CLIPPED and always rescored (eps follows the largest stored norm).  Embeddings with a common
     component, one candidate of 20 x the typical norm (what a propagated low-degree item is at config 5) and 40 more of 2.5-12 x,
-    a query whose best 1,200 candidates tie (> 512 words: overflow -> slow queue), heavy users with k + m below and above what
+    a query whose best 1,200 candidates tie (> 1,024 words: overflow queue, then slow queue), heavy users with k + m below and above what
     the lists hold, against the oracle; the materialised path agrees; two calls are bitwise identical."""
     rng = np.random.default_rng(nq + nc + k)
     Q = (rng.standard_normal((nq, kd)) * 0.2 + 0.1).astype(np.float32)
@@ -804,7 +804,7 @@ def test_topk_filter_subsampled_pass1(ops, dev, nq, nc, k, kd):
     C[big] *= rng.uniform(2.5, 12.0, (40, 1)).astype(np.float32)
     C[5000:5000 + 1200 * 80:80] = 0.7
     Q[7] = 1.0
-    Q[3] = 0.0                                                       # all scores tie at 0: bound below eps -> slow queue
+    Q[3] = 0.0                                                       # all scores are exactly 0: the k lowest unmasked ids
     Q[5] = -Q[5]                                                     # (the outliers are this query's WORST candidates)
     heavy = {11: 150, 13: 420, 19: 3000}
     rows = np.concatenate([rng.integers(0, nq, 10 * nq)] + [np.repeat(q, n) for q, n in heavy.items()] + [np.repeat(21, 20)])
