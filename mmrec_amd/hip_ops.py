@@ -851,6 +851,8 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
         if mask_col is None or mask_col.numel() == 0:
             mask_col = torch.zeros(1, dtype=torch.int32, device=Q.device)
         _chk(mask_col, torch.int32, "mask_col", 1)
+    if nq > 2 * TOPK_QUERY_BLOCK and use_filter and (prepared is not None or lib.mmrec_topk_prepared_bytes(nc, kd) > 0):
+        return _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values)
     idx = torch.empty(nq, k, dtype=torch.int64, device=Q.device)
     val = torch.empty(nq, k, dtype=torch.float32, device=Q.device) if return_values else None
     ws = _ws(lib.mmrec_topk_workspace_bytes(nq, nc, kd, k), Q.device)
@@ -861,6 +863,38 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
         _lib.check(lib.mmrec_score_topk_f32(_p(Q), _p(C), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
                                             _p(idx), _p(val), _p(ws), 0 if use_filter else TOPK_NO_FILTER, _stream()),
                    "score_topk")
+    return (idx, val) if return_values else idx
+
+
+TOPK_QUERY_BLOCK = 65536     # the Trainer's `hip_eval_batch_size`: 256 query blocks x 16 candidate ranges = 8 exact rounds of workgroups
+
+
+def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values):
+    """Very many queries in ONE call (a script ranking all 1M users at once): the fp16 filter's workspace is per query
+    (~16 KB of word list at 500K candidates: 16 GB for 1M queries), so the call is walked in blocks of TOPK_QUERY_BLOCK queries
+    against ONE preparation of the candidates -- what the Trainer's evaluation batches amount to.  One small device -> host
+    read of the blocks' mask offsets (not for use under graph capture)."""
+    nq = Q.shape[0]
+    cands = TopkCandidates.__new__(TopkCandidates)
+    cands.C = C
+    cands.prepared = prepared if prepared is not None else TopkCandidates(C).prepared
+    starts = list(range(0, nq, TOPK_QUERY_BLOCK))
+    offs = None
+    if mask_rowptr is not None:
+        offs = mask_rowptr[torch.tensor(starts + [nq], device=mask_rowptr.device)].cpu().tolist()
+    idx = torch.empty(nq, k, dtype=torch.int64, device=Q.device)
+    val = torch.empty(nq, k, dtype=torch.float32, device=Q.device) if return_values else None
+    for j, a in enumerate(starts):
+        b = min(a + TOPK_QUERY_BLOCK, nq)
+        rp = col = None
+        if mask_rowptr is not None:
+            rp = (mask_rowptr[a:b + 1] - offs[j]).contiguous()
+            col = mask_col[offs[j]:max(offs[j + 1], offs[j] + 1)].contiguous()
+        out = score_topk(Q[a:b], cands, k, rp, col, return_values=return_values)
+        if return_values:
+            idx[a:b], val[a:b] = out
+        else:
+            idx[a:b] = out
     return (idx, val) if return_values else idx
 
 

@@ -863,6 +863,33 @@ def test_topk_filter_overflow_queue(ops, dev):
                 assert set(idx[r].tolist()) == set(ref_i[j].tolist()), r
 
 
+def test_topk_very_many_queries_walked_in_blocks(ops, dev):
+    """150,000 queries in ONE call: hip_ops.score_topk walks them in 65,536-query blocks against one preparation of the
+    candidates (the filter's workspace is per query); the rows at the block seams and a random sample equal the oracle's, and
+    the call equals three separate calls on the blocks bit for bit."""
+    rng = np.random.default_rng(23)
+    nq, nc, k = 150_000, 4500, 10
+    Q = (rng.standard_normal((nq, 64)) * 0.2).astype(np.float32)
+    C = (rng.standard_normal((nc, 64)) * 0.2 + 0.05).astype(np.float32)
+    key = np.unique(np.repeat(np.arange(nq, dtype=np.int64), 3) * nc + rng.integers(0, nc, 3 * nq))
+    mask = np.stack([key // nc, key % nc])
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    Qd, Cd = D(Q, dev), D(C, dev)
+    idx, val = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)
+    sample = np.unique(np.concatenate([[0, 65535, 65536, 65537, 131071, 131072, nq - 1], rng.integers(0, nq, 200)]))
+    scores = torch.from_numpy(Q[sample]) @ torch.from_numpy(C).t()
+    ref_v, ref_i = orc.mask_topk(scores, local_mask_rows(mask, sample), k)
+    np.testing.assert_allclose(val.cpu().numpy()[sample], ref_v.numpy(), rtol=1e-4, atol=1e-5)
+    assert (idx.cpu().numpy()[sample] == ref_i.numpy()).mean() > 0.999
+    rph = rp.cpu().numpy().astype(np.int64)
+    for a in (0, 65536, 131072):
+        b = min(a + 65536, nq)
+        brp = (rp[a:b + 1] - int(rph[a])).contiguous()
+        bcol = col[int(rph[a]):int(rph[b])].contiguous()
+        bi, bv = ops.score_topk(Qd[a:b], Cd, k, brp, bcol, return_values=True)
+        assert torch.equal(bi, idx[a:b]) and torch.equal(bv, val[a:b])
+
+
 def local_mask_rows(mask, rows):
     """the [2, n] mask restricted to the ascending `rows`, row ids relative to the sample"""
     pos = np.searchsorted(rows, mask[0])
