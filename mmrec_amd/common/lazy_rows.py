@@ -134,6 +134,9 @@ class LazyRowEmbedding(nn.Embedding):
         if self._hist.shape[0] < self._t + 1024:
             self._hist = torch.zeros(self._t + 1024, 2, dtype=torch.float32, device=w.device)
         self._pending, self._prefetched = [], None
+        self._owner.fill_(INT_MAX)              # no catch-up is in flight: every owner mark is free
+        if self._overflow is not None:
+            self._overflow.zero_()              # (sticky flag of the run the checkpoint replaces)
 
     def check_overflow(self):
         if self._overflow is not None and int(self._overflow.item()):
@@ -243,7 +246,7 @@ class LazyRowEmbedding(nn.Embedding):
             present = ids >= 0
             slots = self._owner.index_select(0, ids.clamp_min(0)).long()
             slots = torch.where(present, slots, torch.zeros_like(slots))
-            g = torch.zeros_like(dY).index_add_(0, slots, dY * present.unsqueeze(1).to(dY.dtype))
+            g = torch.zeros_like(dY).index_add_(0, slots, torch.where(present.unsqueeze(1), dY, torch.zeros_like(dY)))   # (a NaN row of a skipped slot must not reach slot 0)
         else:
             g = dY
         if self._dev is not None:

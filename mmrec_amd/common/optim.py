@@ -97,7 +97,12 @@ class HipAdam(torch.optim.Optimizer):
             for p in group['params']:
                 table = getattr(p, '_lazy_table', None)
                 if table is not None and p in self.state and self.state[p]:
-                    table.resume(int(self.state[p].get('step', n)))
+                    # the GROUP's count: under hipGraph replay the lazy tables read the group's device counter, so a table
+                    # whose own saved count differed would replay zeroed scalar-table entries (a silent no-op)
+                    if int(self.state[p].get('step', n)) != n:
+                        raise ValueError('HipAdam.load_state_dict: a row-lazy table was saved at step %d, its parameter '
+                                         'group at step %d' % (int(self.state[p]['step']), n))
+                    table.resume(n)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -70,10 +70,12 @@ class Trainer(AbstractTrainer):
         self.fused_eval = True if fused is None else bool(fused)
         dm = config['hip_device_metrics']
         self.device_metrics = True if dm is None else bool(dm)
-        if config['hip_deterministic']:      # new key: bitwise-repeatable training (position-ordered gradient scatters)
-            from mmrec_amd import hip_ops
-            hip_ops.set_deterministic(True)
-            torch.use_deterministic_algorithms(True, warn_only=True)     # the torch ops around the kernels (index_add & co.)
+        # new key: bitwise-repeatable training (position-ordered gradient scatters).  Set from the config value EVERY time a
+        # Trainer is built: the switch is process-wide (hip_ops.DETERMINISTIC), and a later Trainer of the same process --
+        # a hyper-parameter sweep, quick_start's loop -- must not inherit the previous one's choice.
+        from mmrec_amd import hip_ops
+        hip_ops.set_deterministic(hip_ops.DETERMINISTIC_DEFAULT if config['hip_deterministic'] is None
+                                  else bool(config['hip_deterministic']))
 
     def _build_optimizer(self):
         kinds = {'adam': optim.Adam, 'sgd': optim.SGD, 'adagrad': optim.Adagrad, 'rmsprop': optim.RMSprop}

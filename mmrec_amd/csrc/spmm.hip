@@ -246,7 +246,14 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
         const int c0 = long_chunk_ptr[lo], c1 = long_chunk_ptr[lo + 1];
         if (!tickets || c1 - c0 == 1) return;     // uniform
         if (threadIdx.x < 64) {                    // the wave of group 0
+            // The hand-off is hardware ordering, not the HSA memory model's (which would ask for an agent-scope release:
+            // the L2 write-back this scheme exists to avoid): the sc1 stores above are complete at the device's coherence
+            // point when vmcnt reaches 0, and only then is the ticket taken.  The two signal fences pin that order for the
+            // COMPILER (it must not sink a store below the wait or hoist the atomic above it); hip_ops.CsrGraph.checked()
+            // re-zeroes the tickets after a failed launch; tests compare this form with the two-launch form bit for bit.
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __builtin_amdgcn_s_waitcnt(0);         // my partial is out (vmcnt(0))
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (threadIdx.x == 0)
                 s_last = __hip_atomic_fetch_add(tickets + lo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c1 - c0 - 1;

@@ -393,7 +393,10 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
     // them the compiler could not count the loads in flight and drained them all (s_waitcnt vmcnt(0)) before every LDS
     // store and every list append -- the four-tile prefetch distance was one stage's MFMAs in practice.
     auto gload = [&](int uu, uint4& xa, uint4& xb) __attribute__((always_inline)) {     // micro-step u -> its tile
-        const int u = min(uu, u1 - 1);
+        // past the end: the LAST STAGE's tile of the same column block (u0 is a multiple of KB).  Clamping to u1 - 1 alone
+        // would hand column block KB - 1 to a kb == 0 micro-step of kd = 128: c[64:128] . q[0:64] is no candidate's score,
+        // and pass 1 would take its group maxima -- and the bound -- from it.
+        const int u = uu < u1 ? uu : u1 - KB + (uu - u0) % KB;
         const int tv = u / KB, kb = u - tv * KB;
         const size_t o = (((size_t)(t0 + (tv - t0) * S) * KB + kb) * 64 + rr) * 8 + cc;
         xa = a.Cs[o];

@@ -41,12 +41,22 @@ BPR_LOGSIG, BPR_GAMMA = 0, 1
 # training run is not bitwise repeatable, although the reference's CPU path is.  In deterministic mode the same
 # kernels run on the batch's GATHERED rows with identity ids (every output row written once) and the rows are scattered into
 # the tables by mmrec_scatter_add_rows_sorted_f32: duplicates summed in position order by one owner, no atomics.
-DETERMINISTIC = False
+DETERMINISTIC_DEFAULT = False     # what `hip_deterministic: null` means (the Trainer passes the config value on every build)
+DETERMINISTIC = DETERMINISTIC_DEFAULT
+_TORCH_DET_BY_US = False
 
 
 def set_deterministic(flag=True):
-    global DETERMINISTIC
+    """Process-wide switch.  Also puts torch's own scatter ops around the kernels (index_add & co.) into their
+    deterministic mode -- and takes them out of it again only if this function put them there."""
+    global DETERMINISTIC, _TORCH_DET_BY_US
     DETERMINISTIC = bool(flag)
+    if DETERMINISTIC and not torch.are_deterministic_algorithms_enabled():
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        _TORCH_DET_BY_US = True
+    elif not DETERMINISTIC and _TORCH_DET_BY_US:
+        torch.use_deterministic_algorithms(False)
+        _TORCH_DET_BY_US = False
 
 
 def scatter_add_rows(ids, rows, out):
@@ -135,6 +145,19 @@ class CsrGraph:
             self.long_rows = self.long_chunk_ptr = self.long_tickets = None
         self._partials = {}
 
+    def checked(self, rc, what):
+        """_lib.check for a launch that uses the last-arriver tickets: they are left at zero by every COMPLETED launch; after a
+        failed one they are re-zeroed here, or every later SpMM on this graph would finish its long rows on a stale count."""
+        try:
+            _lib.check(rc, what)
+        except _lib.MMRecHipError:
+            if self.long_tickets is not None:
+                try:
+                    self.long_tickets.zero_()
+                except RuntimeError:
+                    pass                         # (a faulted device: nothing more will run on it anyway)
+            raise
+
     def partials_for(self, d):
         """long-row workspace (n_chunks x d fp32), allocated once per embedding width"""
         if self.n_long == 0:
@@ -211,11 +234,11 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
             _chk(t, torch.float32, nm, 2)
             if t.shape[0] < g.n_rows or t.shape[1] != d:
                 raise _lib.MMRecHipError("%s must be [>=%d, %d]" % (nm, g.n_rows, d))
-    _lib.check(lib.mmrec_spmm_csr_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Y), _p(Z),
-                                      _p(acc_in), _p(acc_out), g.n_rows, d, float(alpha),
-                                      float(beta), float(acc_scale), g.long_row_threshold,
-                                      _p(g.long_rows), _p(g.long_chunk_ptr), g.n_long, g.n_chunks,
-                                      _p(g.partials_for(d)), _p(g.long_tickets), _stream()), "spmm_csr_f32")
+    g.checked(lib.mmrec_spmm_csr_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Y), _p(Z),
+                                     _p(acc_in), _p(acc_out), g.n_rows, d, float(alpha),
+                                     float(beta), float(acc_scale), g.long_row_threshold,
+                                     _p(g.long_rows), _p(g.long_chunk_ptr), g.n_long, g.n_chunks,
+                                     _p(g.partials_for(d)), _p(g.long_tickets), _stream()), "spmm_csr_f32")
     return Y if Y is not None else acc_out
 
 
@@ -363,7 +386,7 @@ class _LayerGCNSum(torch.autograd.Function):
         for layer in range(L):                    # SpMM + cosine re-weighting + layer sum: ONE launch per layer
             y = torch.empty_like(E0) if need_y else None
             out, w = torch.empty_like(E0), torch.empty(n, dtype=torch.float32, device=E0.device)
-            _lib.check(lib.mmrec_spmm_csr_f32_layergcn(
+            g.checked(lib.mmrec_spmm_csr_f32_layergcn(
                 _p(g.rowptr), _p(g.colidx), _p(g.vals), _p(cur), _p(y), _p(E0), _p(out), _p(w),
                 _p(acc) if layer > 0 else None, _p(acc), g.n_rows, EMB_DIM, g.long_row_threshold, _p(g.long_rows),
                 _p(g.long_chunk_ptr), g.n_long, g.n_chunks, _p(g.partials_for(EMB_DIM)), _p(g.long_tickets), _stream()),

@@ -82,14 +82,43 @@ def knn_item_graph(feats, k):
     xn = x.div(torch.norm(x, p=2, dim=-1, keepdim=True))
     sim = torch.mm(xn, xn.t())
     _, knn = torch.topk(sim, k, dim=-1)
-    n = x.shape[0]
+    idx, val = knn_laplacian_values(knn)
+    return idx, val, knn.numpy()
+
+
+def knn_laplacian_values(knn):
+    """models/freedom.py:86-100 (`compute_normalized_laplacian`) for given neighbour lists knn [I, k]: (rows, cols) in row-major
+    order and D^-1/2 A D^-1/2 values with D = row sums of the 0/1 adjacency + 1e-7 (fp32).  -> (idx [2, I*k] int64, val fp32)."""
+    knn = torch.as_tensor(knn, dtype=torch.int64)
+    n, k = knn.shape
     rows = torch.arange(n).unsqueeze(1).expand(-1, k).reshape(-1)
     cols = knn.reshape(-1)
     row_sum = 1e-7 + torch.zeros(n, dtype=torch.float32).index_add_(
         0, rows, torch.ones(rows.shape[0], dtype=torch.float32))
     r_inv = torch.pow(row_sum, -0.5)
     val = r_inv[rows] * r_inv[cols]
-    return torch.stack([rows, cols]).numpy(), val.numpy(), knn.numpy()
+    return torch.stack([rows, cols]).numpy(), val.numpy()
+
+
+def knn_rows(feats, rows, k, chunk=32768):
+    """The rows `rows` of models/freedom.py:80-84 -- `sim = mm(context_norm, context_norm^T)`, `topk(sim, k)` -- for item
+    counts whose [I, I] similarity block cannot be formed (config 5: 1 TB): a row of `sim` depends on its own query row
+    only, so the sampled rows are the reference's rows.  Candidates are walked in chunks; besides the reference's fp32
+    scores the float64 scores of the same normalised rows are returned (to judge near-ties by).
+    Returns (knn [len(rows), k] int64, sim32 [len(rows), I] fp32, sim64 [len(rows), I] float64, xn [I, F] fp32)."""
+    x = torch.as_tensor(feats, dtype=torch.float32)
+    xn = x.div(torch.norm(x, p=2, dim=-1, keepdim=True))
+    rows = torch.as_tensor(np.asarray(rows), dtype=torch.int64)
+    q = xn[rows]
+    q64 = q.double()
+    sim32 = torch.empty(rows.shape[0], x.shape[0], dtype=torch.float32)
+    sim64 = torch.empty(rows.shape[0], x.shape[0], dtype=torch.float64)
+    for a in range(0, x.shape[0], chunk):
+        c = xn[a:a + chunk]
+        torch.mm(q, c.t(), out=sim32[:, a:a + chunk])
+        torch.mm(q64, c.double().t(), out=sim64[:, a:a + chunk])
+    _, knn = torch.topk(sim32, k, dim=-1)
+    return knn, sim32, sim64, xn
 
 
 def freedom_mm_adj(image_feat, text_feat, k, image_weight):

@@ -30,6 +30,7 @@ import pytest
 import torch
 
 from oracle import mmrec_oracle as orc
+from tests._env import observed
 
 pytestmark = pytest.mark.gpu
 
@@ -251,7 +252,7 @@ def check_eval(model, valid_data, u_ref, i_ref, n_sample):
     log("oracle scores + mask + top-50 on the CPU: %.1fs" % (time.time() - t))
     # same ids up to near-ties at the cut (untrained embeddings: densely packed scores, another fp32 summation order)
     same = np.mean([set(a) == set(b) for a, b in zip(idx_np.tolist(), ref_i.tolist())])
-    assert same >= 0.98, same
+    assert observed("c5_e2e.top50_sets_vs_oracle", same, 0.999) >= 0.999, same     # measured 0.9999 (profiles/r03: 10 x the miss rate)
     u_all, i_all = model._cached_eval_embeddings()
     bad = np.flatnonzero([set(a) != set(b) for a, b in zip(idx_np.tolist(), ref_i.tolist())])[:64]
     for j in bad:
@@ -353,7 +354,7 @@ def test_freedom_c5_step_and_recall_vs_oracle(tmp_path):
         pos = np.searchsorted(rows_all, rows)                     # the 4096 are among the 50,000 (prefix of one permutation)
         assert np.array_equal(rows_all[pos], rows)
         same = np.mean([set(a) == set(b) for a, b in zip(idx_sh.tolist(), idx_plain[pos].tolist())])
-        assert same >= 0.999, same
+        assert observed("c5_e2e.sharded_vs_plain", same, 0.9999) >= 0.9999, same    # the same kernels on the same tables
         log("ShardedFREEDOM (1 rank, forced collectives): loss %.8f == plain %.8f, top-50 of %d users identical %.4f" %
             (float(loss_sh.detach()), loss_plain, rows.shape[0], same))
     finally:

@@ -437,7 +437,8 @@ def _check_eval_against_golden(model, config, valid_data, g, prefix):
         kth = float(torch.topk(s[j], 50)[0][-1])
         for c in a ^ b:
             assert abs(float(s[j][c]) - kth) <= 2e-6 * unit, (prefix, r, c)
-    assert same >= 0.95 * len(rows), same
+    from tests._env import observed
+    assert observed("shapes.%seval_top50_vs_reference" % prefix, same / len(rows), 0.98) >= 0.98, same
 
 
 def test_freedom_step_vs_reference_golden_at_sports_shape(tmp_path):
@@ -460,7 +461,8 @@ def test_freedom_step_vs_reference_golden_at_sports_shape(tmp_path):
     mine = orc.coalesce_coo(*model.mm_adj.to_coo_host(), ni, ni)
     theirs = orc.coalesce_coo(ref_idx, ref_val, ni, ni)
     agree = len(set(map(tuple, mine[0].T)) & set(map(tuple, theirs[0].T))) / theirs[0].shape[1]
-    assert agree > 0.995, agree                        # near-tie neighbours may differ (fp32 accumulation order)
+    from tests._env import observed
+    assert observed("shapes.sports_mm_adj_vs_reference", agree, 0.995) > 0.995, agree                        # near-tie neighbours may differ (fp32 accumulation order)
     model.mm_adj = hip_ops.CsrGraph.from_coo_host(ref_idx, ref_val, ni, ni, dev)
     model.mm_adj.transpose()
     model.set_kept_edges(torch.as_tensor(g["fr_keep_idx"].astype(np.int64)).to(dev))

@@ -955,6 +955,33 @@ def test_topk_filter_rows_of_128(ops, dev, nq, nc, k):
     np.testing.assert_allclose(a[1][:, :min(k, 64)].cpu().numpy(), m[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("nq,nc,k", [(300, 40_037, 50), (300, 40_037, 10), (130, 149_900, 20)])
+def test_topk_filter_rows_of_128_padding_steps_score_real_candidates(ops, dev, nq, nc, k):
+    """Round-3 advice: with kd = 128 a candidate range that holds an ODD number of whole stages (40,037: 25 in the last of 16
+    ranges; 149,900: 61 virtual stages at pass-1 stride 2) ends pass 1's four-micro-step loop with two padding steps.  They
+    used to re-load tile (last stage, column block 1) for BOTH column blocks: c[64:128] . q[0:64] + c[64:128] . q[64:128] --
+    no candidate's score -- went into the group maxima and so into the bound.  Adversarial data for exactly that: the last
+    whole stages' candidates are large in columns 64..127 along the direction the queries are large in in columns 0..63
+    (bogus score ~ +60 against true scores of ~ 1), several masked items per query (k + m above the 32 groups of a range,
+    so the inflated maxima would shift the rank the bound is read at).  Against orc.mask_topk."""
+    rng = np.random.default_rng(nc + k)
+    v = rng.standard_normal(64).astype(np.float32)
+    v /= np.linalg.norm(v)
+    Q = (rng.standard_normal((nq, 128)) * 0.1).astype(np.float32)
+    Q[:, :64] += 8.0 * v                                  # queries: large along v in the FIRST column block
+    C = (rng.standard_normal((nc, 128)) * 0.1).astype(np.float32)
+    whole = nc // 64 * 64
+    C[whole - 192:whole, 64:] += 8.0 * v                  # last whole stages: large along v in the SECOND column block
+    rows = np.concatenate([rng.integers(0, nq, 30 * nq), np.repeat(np.arange(0, nq, 7), 40)])
+    cols = np.concatenate([rng.integers(0, nc, 30 * nq), rng.integers(0, nc, 40 * len(range(0, nq, 7)))])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    idx = _topk_check(ops, dev, Q, C, k, mask, exact_gap=2e-5)
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    m = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, use_filter=False)
+    assert np.mean(m.cpu().numpy() == idx) > 0.999       # the materialised fp32 path agrees
+
+
 @pytest.mark.parametrize("nq,nc", [(700, 7050), (300, 40_037), (100, 3000)])
 def test_topk_prepared_candidates_identical(ops, dev, nq, nc):
     """mmrec_score_topk_prepared_f32 (ABI 7): the candidate side of the fp16 filter computed ONCE (hip_ops.TopkCandidates)
