@@ -49,7 +49,10 @@ const char* mmrec_error_string(int err);
  * A is CSR (rowptr[n_rows+1], colidx[nnz], vals[nnz]) with n_rows local rows whose column ids index
  * rows of X (any number of X rows; a rank of a row-sharded graph passes its row block here).
  * d must be a multiple of 64, at most 384 (64 for the d = 64 graph models; 256 / 384 for MMGCN's
- * modality layers).  Rows are summed in CSR order, a fixed order that does not depend on how rows are
+ * modality layers) -- or 8, 16 or 32: ONE FEATURE SLICE of a 64-wide table (X, Y, Z, acc_* are [rows, d] row-major slices;
+ * the feature-sliced multi-GPU layout, where a rank owns 64 / P columns of every table and the whole graph: a column's
+ * sum is the d = 64 launch's, operation for operation, so the P slices ARE the columns of the single-GPU result).
+ * Rows are summed in CSR order, a fixed order that does not depend on how rows are
  * partitioned over GPUs, so sharded == single-GPU bit for bit.
  *
  * Rows longer than `long_row_threshold` are not handled by the row kernel; the caller lists them

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libmmrec_hip.so")
-SOURCES = ["api.hip", "spmm.hip", "bpr.hip", "infonce.hip", "gemm.hip", "topk.hip", "topk_filter.hip", "graph.hip", "evalsample.hip", "adam.hip"]
+SOURCES = ["api.hip", "spmm.hip", "spmm_narrow.hip", "bpr.hip", "infonce.hip", "gemm.hip", "topk.hip", "topk_filter.hip", "graph.hip", "evalsample.hip", "adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 EXTRA_FLAGS = {}    # per-file extras: {source name: [flags]}
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, h) for h in ("common.h", "mfma_stream.h", "topk_sort.h", "topk_filter.h")] + [
+    deps = [os.path.join(CSRC, h) for h in ("common.h", "mfma_stream.h", "topk_sort.h", "topk_filter.h", "spmm_narrow.h")] + [
         os.path.join(PKG, "..", "include", "mmrec_hip.h")]
     jobs = []
     for s in SOURCES:

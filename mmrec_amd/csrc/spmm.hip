@@ -16,6 +16,7 @@
 // from being bound by the latency of their longest row.  No float atomics:
 // the per-row summation order is fixed and independent of the row partition (multi-GPU == 1 GPU).
 #include "common.h"
+#include "spmm_narrow.h"
 
 // tools/spmm_lab.py builds this file with a cache-policy mask (the library only ever uses MMREC_SPMM_POLICY below):
 // bit0 colidx / vals streamed with nontemporal loads, bit1 Y / acc written with nontemporal stores, bit2 X rows gathered
@@ -28,6 +29,11 @@
 // matrix rows per 16-lane group of a row block (tools/spmm_sweep.py overrides it)
 #ifndef MMREC_SPMM_RPG
 #define MMREC_SPMM_RPG(n_rows) ((n_rows) <= (1 << 18) ? 1 : 4)
+#endif
+// rows of a group walked TOGETHER when rows-per-group equals this (0 / 1: one after the other), X rows prefetched per row
+#ifndef MMREC_SPMM_RB
+#define MMREC_SPMM_RB 0
+#define MMREC_SPMM_PF 4
 #endif
 
 namespace {
@@ -86,9 +92,10 @@ struct RowEpilogue {
     float* w_out;
 };
 
-template <int DCH>
+// LG: the LayerGCN epilogue, its own instantiation -- compiled into the common kernel its registers cost every launch occupancy
+template <int DCH, bool LG>
 __device__ __forceinline__ void store_row(const RowEpilogue& ep, int row, int lane16, const float4 (&sum)[DCH]) {
-    if (DCH == 1 && ep.ego) {   // the 16 lanes of the group hold the whole 64-float row: the row statistics are 4 DPP steps
+    if (DCH == 1 && LG) {   // the 16 lanes of the group hold the whole 64-float row: the row statistics are 4 DPP steps
         const size_t off = (size_t)row * 16 + lane16;
         const float4 y = f4_scale(ep.alpha, sum[0]);
         const float4 g = reinterpret_cast<const float4*>(ep.ego)[off];
@@ -162,7 +169,7 @@ __device__ __forceinline__ void gather_span(const int32_t* __restrict__ colidx,
 // a fixed-order LDS tree over the 16 groups (the heaviest C5 row has 280 chunks; a single sequential chain over them
 // would cost ~110 us); group 0 finishes the row.  ONE order for both callers -- the reduce kernel and the last-arriver
 // chunk block -- so the two forms give the same bits.
-template <int DCH, bool COHERENT>
+template <int DCH, bool COHERENT, bool LG>
 __device__ __forceinline__ void reduce_long_row(const float* __restrict__ partials, int c0, int c1, int row,
                                                 const RowEpilogue& ep, float4 (*red)[16 * DCH]) {
     const int lane16 = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -184,13 +191,88 @@ __device__ __forceinline__ void reduce_long_row(const float* __restrict__ partia
 #pragma unroll
             for (int k = 1; k < 16; ++k) r[ch] = f4_add(r[ch], red[k][ch * 16 + lane16]);
         }
-        store_row<DCH>(ep, row, lane16, r);
+        store_row<DCH, LG>(ep, row, lane16, r);
+    }
+}
+
+// The RB short rows of a 16-lane group TOGETHER (d = 64): the row kernel's chain per row is rowptr -> (col, val) -> X rows ->
+// store, three dependent memory round trips, and a group that walks its rows one after the other exposes all of them per
+// row -- the pruned training graph of config 5 (4M nnz over 1.5M rows: 2.7 per row) ran at half the rate of the 13-per-row
+// headline graph (profiles/r04_spmm_rows_batched.log).  Here the RB row extents are read at once, then the first 16
+// (col, val) pairs of every row, then the first PF X rows of every row (RB x PF gathers in flight per group); the rest of a
+// row, if any, follows row by row as before.  A row's terms are added in the same order as ever: same bits.
+template <int RB, int PF, bool LG>
+__device__ __forceinline__ void rows_batched(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                             const float* __restrict__ vals, const float4* __restrict__ X4,
+                                             const RowEpilogue& ep, int n_rows, int long_t, int row0, int lane16) {
+    int s[RB], n[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = row0 + i * 16;
+        s[i] = 0;
+        n[i] = -1;                               // no such row
+        if (row < n_rows) {
+            s[i] = rowptr[row];
+            n[i] = rowptr[row + 1] - s[i];
+        }
+    }
+    int c[RB];
+    float v[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        if (n[i] > long_t) n[i] = -1;            // handled by the chunk blocks
+        c[i] = 0;
+        v[i] = 0.f;
+        if (lane16 < n[i]) {
+            c[i] = ld_stream(colidx + s[i] + lane16);
+            v[i] = ld_stream(vals + s[i] + lane16);
+        }
+    }
+    // EVERY X-row load below is unconditional -- a slot past the row's end re-reads the row's last column (an L1 hit; column
+    // 0 for an empty row) and a select drops the value: with `(u < n) ? load : 0` the compiler put each load into its own
+    // branch and, in the loop, drained it (s_waitcnt vmcnt(0)) before issuing the next one.
+    float4 x[RB][PF];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int last = max(min(n[i], 16), 1) - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int cj = __shfl(c[i], min(u, last), 16);
+            x[i][u] = ld_x(X4 + (size_t)cj * 16 + lane16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        if (n[i] < 0) continue;                  // uniform within the group
+        float4 acc[1] = {f4_zero()};
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {           // (slots past the end: v = 0 there, and the select keeps a non-finite X row out)
+            const float4 xu = (u < n[i]) ? x[i][u] : f4_zero();
+            acc[0] = f4_fma(__shfl(v[i], u, 16), xu, acc[0]);
+        }
+        const int cnt = min(16, n[i]);
+        for (int j0 = PF; j0 < cnt; j0 += 8) {   // the rest of the first window, 8 gathers in flight
+            float4 y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cj = __shfl(c[i], min(j0 + u, cnt - 1), 16);
+                y[u] = ld_x(X4 + (size_t)cj * 16 + lane16);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const float vv = (j < 16) ? __shfl(v[i], j & 15, 16) : 0.f;
+                acc[0] = f4_fma(vv, (j < cnt) ? y[u] : f4_zero(), acc[0]);
+            }
+        }
+        if (n[i] > 16) gather_span<1>(colidx, vals, X4, s[i] + 16, s[i] + n[i], lane16, acc);
+        store_row<1, LG>(ep, row0 + i * 16, lane16, acc);
     }
 }
 
 // One launch covers both kinds of work: blocks [0, n_chunks) reduce one long-row chunk each (started
 // first: they are the longest dependency chains), blocks [n_chunks, ...) process 64 short rows each.
-template <int DCH>
+template <int DCH, bool LG>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
     const float* __restrict__ vals, const float* __restrict__ X, RowEpilogue ep, int n_rows,
@@ -229,7 +311,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
                 for (int i = 1; i < 16; ++i) t[ch] = f4_add(t[ch], red[i][ch * 16 + lane16]);
             }
             if (long_chunk_ptr[lo + 1] - long_chunk_ptr[lo] == 1) {
-                store_row<DCH>(ep, row, lane16, t);  // the whole row fitted one chunk: done
+                store_row<DCH, LG>(ep, row, lane16, t);  // the whole row fitted one chunk: done
             } else {
 #pragma unroll
                 for (int ch = 0; ch < DCH; ++ch) {
@@ -261,11 +343,16 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
         __syncthreads();
         if (!s_last) return;                       // uniform
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        reduce_long_row<DCH, true>(partials, c0, c1, row, ep, red);
+        reduce_long_row<DCH, true, LG>(partials, c0, c1, row, ep, red);
         if (threadIdx.x == 0) __hip_atomic_store(tickets + lo, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const int row0 = ((int)blockIdx.x - n_chunks) * 16 * rows_per_group + g;
+    if (DCH == 1 && MMREC_SPMM_RB > 1 && rows_per_group == MMREC_SPMM_RB) {
+        rows_batched<(MMREC_SPMM_RB > 1 ? MMREC_SPMM_RB : 2), MMREC_SPMM_PF, LG>(rowptr, colidx, vals, X4, ep, n_rows, long_t, row0,
+                                                                             lane16);
+        return;
+    }
 #pragma unroll 1
     for (int i = 0; i < rows_per_group; ++i) {
         const int row = row0 + i * 16;
@@ -276,12 +363,12 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 #pragma unroll
         for (int ch = 0; ch < DCH; ++ch) acc[ch] = f4_zero();
         gather_span<DCH>(colidx, vals, X4, s, e, lane16, acc);
-        store_row<DCH>(ep, row, lane16, acc);
+        store_row<DCH, LG>(ep, row, lane16, acc);
     }
 }
 
 // One workgroup per long row that spans several chunks (the two-launch form: large graphs).
-template <int DCH>
+template <int DCH, bool LG>
 __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(
     const int32_t* __restrict__ long_rows, const int32_t* __restrict__ long_chunk_ptr, int n_long,
     const float* __restrict__ partials, RowEpilogue ep) {
@@ -289,18 +376,18 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(
     const int i = blockIdx.x;
     const int c0 = long_chunk_ptr[i], c1 = long_chunk_ptr[i + 1];
     if (c1 - c0 <= 1) return;  // uniform for the block: single-chunk rows were finished by their chunk block
-    reduce_long_row<DCH, false>(partials, c0, c1, long_rows[i], ep, red);
+    reduce_long_row<DCH, false, LG>(partials, c0, c1, long_rows[i], ep, red);
 }
 
-template <int DCH>
+template <int DCH, bool LG = false>
 void launch_spmm(hipStream_t s, int blocks, int nch, const int32_t* rowptr, const int32_t* colidx,
                  const float* vals, const float* X, const RowEpilogue& ep, int n_rows, int long_t,
                  int rows_per_group, const int32_t* long_rows, const int32_t* long_chunk_ptr, int n_long,
                  float* partials, int32_t* tickets) {
-    hipLaunchKernelGGL(spmm_rows_kernel<DCH>, dim3(blocks + nch), dim3(256), 0, s, rowptr, colidx, vals, X,
+    hipLaunchKernelGGL((spmm_rows_kernel<DCH, LG>), dim3(blocks + nch), dim3(256), 0, s, rowptr, colidx, vals, X,
                        ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, nch, partials, tickets);
     if (!tickets && n_long > 0 && nch > n_long)  // at least one row spans several chunks
-        hipLaunchKernelGGL(spmm_long_reduce_kernel<DCH>, dim3(n_long), dim3(256), 0, s, long_rows,
+        hipLaunchKernelGGL((spmm_long_reduce_kernel<DCH, LG>), dim3(n_long), dim3(256), 0, s, long_rows,
                            long_chunk_ptr, n_long, partials, ep);
 }
 
@@ -364,7 +451,8 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
                                   const int32_t* long_rows, const int32_t* long_chunk_ptr,
                                   int32_t n_long, int32_t n_chunks, float* partials, int32_t* long_tickets,
                                   mmrec_stream_t stream) {
-    if (d <= 0 || d % MMREC_EMB_DIM || d / MMREC_EMB_DIM > 6) return MMREC_ERR_UNSUPPORTED;
+    const bool narrow = d == 8 || d == 16 || d == 32;      // one feature slice of a 64-wide table (spmm_narrow.hip)
+    if (!narrow && (d <= 0 || d % MMREC_EMB_DIM || d / MMREC_EMB_DIM > 6)) return MMREC_ERR_UNSUPPORTED;
     if (n_rows < 0 || n_long < 0 || n_chunks < 0 || long_row_threshold < 0) return MMREC_ERR_BAD_ARG;
     if (n_rows == 0) return 0;
     if (!rowptr || !X || (!Y && !acc_out)) return MMREC_ERR_BAD_ARG;
@@ -372,6 +460,10 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     if (n_long > 0 && (!long_rows || !long_chunk_ptr || !partials || n_chunks <= 0))
         return MMREC_ERR_BAD_ARG;
     if (Y == X) return MMREC_ERR_BAD_ARG;  // other rows still gather from X
+    if (narrow)
+        return spmm_narrow_launch(rowptr, colidx, vals, X, Y, Z, acc_in, acc_out, n_rows, d, alpha, beta, acc_scale,
+                                  n_long > 0 ? long_row_threshold : INT32_MAX, long_rows, long_chunk_ptr, n_long,
+                                  n_long > 0 ? n_chunks : 0, partials, mmrec_stream(stream));
     RowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale, nullptr, nullptr, nullptr};
     hipStream_t s = mmrec_stream(stream);
     // small (cache-resident, latency-bound) graphs: one row per 16-lane group; large graphs: four
@@ -418,8 +510,8 @@ extern "C" int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t*
     const int long_t = n_long > 0 ? long_row_threshold : INT32_MAX;
     const int nch = n_long > 0 ? n_chunks : 0;
     int32_t* tickets = (n_long > 0 && n_rows <= MMREC_SPMM_FUSED_REDUCE_MAX_ROWS) ? long_tickets : nullptr;
-    launch_spmm<1>(s, blocks, nch, rowptr, colidx, vals, X, ep, n_rows, long_t, rows_per_group, long_rows,
-                   long_chunk_ptr, n_long, partials, tickets);
+    launch_spmm<1, true>(s, blocks, nch, rowptr, colidx, vals, X, ep, n_rows, long_t, rows_per_group, long_rows,
+                         long_chunk_ptr, n_long, partials, tickets);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

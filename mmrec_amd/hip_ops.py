@@ -17,6 +17,7 @@ import torch
 from . import _lib
 
 EMB_DIM = 64
+SLICE_WIDTHS = (8, 16, 32)    # one feature slice of a 64-wide table: 64 / P columns per rank of the feature-sliced layout (csrc/spmm_narrow.hip)
 SPMM_CHUNK = 512
 LONG_ROW_DEFAULT = None    # by graph size, see default_long_row_threshold
 
@@ -227,8 +228,9 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
     lib = _lib.load()
     _chk(X, torch.float32, "X", 2)
     d = X.shape[1]
-    if d % EMB_DIM or d > 6 * EMB_DIM or X.shape[0] < g.n_cols:
-        raise _lib.MMRecHipError("X must be [>=%d, 64*k <= 384], got %s" % (g.n_cols, tuple(X.shape)))
+    if (d not in SLICE_WIDTHS and (d % EMB_DIM or d > 6 * EMB_DIM)) or X.shape[0] < g.n_cols:
+        raise _lib.MMRecHipError("X must be [>=%d, 64*k <= 384 (or a feature slice of 8 / 16 / 32 columns)], got %s" %
+                                 (g.n_cols, tuple(X.shape)))
     for t, nm in ((Y, "Y"), (Z, "Z"), (acc_in, "acc_in"), (acc_out, "acc_out")):
         if t is not None:
             _chk(t, torch.float32, nm, 2)
@@ -269,7 +271,7 @@ def spmm(g: CsrGraph, X, Z=None):
     mean-aggregating propagate (mmgcn.py:205-213).  Row widths that are not a multiple of 64 are
     zero-padded for the kernel (aggregation is column-wise independent) and sliced back."""
     d = X.shape[1]
-    if d % EMB_DIM:
+    if d % EMB_DIM and d not in SLICE_WIDTHS:
         pad = EMB_DIM - d % EMB_DIM
         Xp = torch.nn.functional.pad(X, (0, pad))
         Zp = None if Z is None else torch.nn.functional.pad(Z, (0, pad))

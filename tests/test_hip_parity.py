@@ -130,6 +130,64 @@ def test_spmm_row_shards_bitwise_equal(ops, dev):
         assert torch.equal(Yb, Y[r0:r1])
 
 
+@pytest.mark.parametrize("n_rows,thr", [(777, 8), (777, 256), (300_000, None)])
+def test_spmm_feature_slices_equal_the_d64_launch_bitwise(ops, dev, n_rows, thr):
+    """The feature-sliced multi-GPU layout (csrc/spmm_narrow.hip): a rank owns 64 / P columns of every table
+    and the whole graph, `Y[:, s] = A X[:, s]` needs no exchange.  World 1 here: the P = 2 / 4 / 8 slices ([n, 32 / 16 / 8]
+    contiguous) through mmrec_spmm_csr_f32 one after the other == the columns of the d = 64 launch BIT FOR BIT -- short
+    rows, empty rows, single-chunk and multi-chunk long rows (both sides of the chunk size), both row-finish forms of the
+    d = 64 kernel (last-arriver up to 2^18 rows, two launches above), plain and full epilogue (alpha, beta Z, running sum)."""
+    rng = np.random.default_rng(n_rows)
+    n_cols = n_rows if n_rows > 1000 else 500
+    degs = rng.integers(0, 40, n_rows)
+    degs[[5, 6, 100, 101, 102, 103, n_rows - 1]] = [0, 1, 5000, 512, 513, 20_000, 300]
+    idx, val = _random_csr(rng, n_rows, n_cols, degs)
+    g = ops.CsrGraph.from_coo_host(idx, val, n_rows, n_cols, dev, long_row_threshold=thr)
+    assert g.n_long > 0 and g.n_chunks > g.n_long
+    X = D(rng.standard_normal((n_cols, 64)).astype(np.float32), dev)
+    Z = D(rng.standard_normal((n_rows, 64)).astype(np.float32), dev)
+    A0 = D(rng.standard_normal((n_rows, 64)).astype(np.float32), dev)
+    Y, Y2, acc = (torch.empty(n_rows, 64, device=dev) for _ in range(3))
+    ops.spmm_raw(g, X, Y=Y)
+    ops.spmm_raw(g, X, Y=Y2, Z=Z, acc_in=A0, acc_out=acc, alpha=0.5, beta=2.0, acc_scale=0.25)
+    for P in (2, 4, 8):
+        w = 64 // P
+        for s in range(P):
+            cols = slice(s * w, (s + 1) * w)
+            Xs, Zs, As = X[:, cols].contiguous(), Z[:, cols].contiguous(), A0[:, cols].contiguous()
+            Ys, Y2s, accs = (torch.full((n_rows, w), float("nan"), device=dev) for _ in range(3))
+            ops.spmm_raw(g, Xs, Y=Ys)
+            assert torch.equal(Ys, Y[:, cols]), (P, s)
+            ops.spmm_raw(g, Xs, Y=Y2s, Z=Zs, acc_in=As, acc_out=accs, alpha=0.5, beta=2.0, acc_scale=0.25)
+            assert torch.equal(Y2s, Y2[:, cols]) and torch.equal(accs, acc[:, cols]), (P, s)
+            ops.spmm_raw(g, Xs, acc_in=As, acc_out=accs)                  # Y = NULL: the running sum alone
+            assert torch.equal(accs, As + Y[:, cols]), (P, s)
+    assert torch.all(Y[5] == 0)
+    with pytest.raises(Exception):
+        ops.spmm_raw(g, X[:, :24].contiguous(), Y=torch.empty(n_rows, 24, device=dev))     # not a slice width
+
+
+def test_lightgcn_mean_on_feature_slices_forward_and_backward_bitwise(ops, dev):
+    """hip_ops.lightgcn_mean (freedom.py:169-176) per feature slice == its columns on the full tables, forward AND backward
+    (the Horner recurrence on A^T is column-wise independent too), on the Amazon-Baby-shaped graph, P = 8."""
+    from mmrec_amd import synth
+    nu, ni, eu, ei = synth.shaped_edges("baby", seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    n = nu + ni
+    g = ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
+    gen = torch.Generator().manual_seed(1)
+    E0 = (torch.randn(n, 64, generator=gen) * 0.1).to(dev).requires_grad_()
+    G = (torch.randn(n, 64, generator=gen)).to(dev)
+    out = ops.lightgcn_mean(g, E0, 2)
+    out.backward(G)
+    for s in range(8):
+        cols = slice(8 * s, 8 * s + 8)
+        Es = E0.detach()[:, cols].contiguous().requires_grad_()
+        o = ops.lightgcn_mean(g, Es, 2)
+        o.backward(G[:, cols].contiguous())
+        assert torch.equal(o.detach(), out.detach()[:, cols]) and torch.equal(Es.grad, E0.grad[:, cols]), s
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_spmm_last_arriver_row_finish_equals_two_launches(ops, dev, d):
     """Graphs of <= 2^18 rows finish a multi-chunk row INSIDE the launch (mmrec_spmm_csr_f32 `long_tickets`, ABI 7: the chunk

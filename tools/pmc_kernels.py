@@ -4,6 +4,8 @@
 
     python tools/pmc_kernels.py topk   [out_prefix]     # score_topk: Baby full evaluation + a 65,536 x 500,000 block
     python tools/pmc_kernels.py linear [out_prefix]     # 4096 -> 64 projection fwd / dW / dX at Baby, Clothing, C5 item counts
+    python tools/pmc_kernels.py spmm   [out_prefix]     # CSR SpMM on the config-5 graphs (full / 80 %-pruned / item-item), d = 64 and the
+                                                        # feature slices d = 32 / 8: memory-side counters (requests by size, TLB, TA / TCP stalls)
 
 Per kernel (matched by substring, grouped by grid size): calls, mean duration, mean counter values, and the derived
 MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES-equivalent: duration x clock x SIMDs), reported both ways."""
@@ -52,6 +54,36 @@ def child_topk():
     torch.cuda.synchronize()
 
 
+SPMM_SETS = [
+    ["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"],
+    ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"], ["TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
+    ["TCC_EA0_RDREQ_DRAM_sum", "TCC_REQ_sum"], ["TCC_EA0_RDREQ_LEVEL_sum", "TCC_TAG_STALL_sum"],
+    ["TCP_UTCL1_TRANSLATION_MISS_sum", "TCP_UTCL1_TRANSLATION_HIT_sum"],
+    ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"],
+    ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_PENDING_STALL_CYCLES_sum"],
+    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VMEM_RD",
+     "SQ_INST_LEVEL_VMEM"],
+    ["TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum"], ["TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_BUSY_avr"],
+]
+
+
+def child_spmm():
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mmrec_amd import hip_ops
+    from spmm_rows_lab import graphs
+    dev = torch.device("cuda:0")
+    for name, (g, n_x) in graphs(dev).items():
+        for d in (64, 32, 8):
+            x = torch.rand(n_x, d, device=dev) - 0.5
+            y = torch.empty(g.n_rows, d, device=dev)
+            for _ in range(3):
+                hip_ops.spmm_raw(g, x, Y=y)
+            torch.cuda.synchronize()
+        print("[pmc-spmm] %s: rows %d nnz %d chunks %d" % (name, g.n_rows, g.nnz, g.n_chunks), file=sys.stderr, flush=True)
+
+
 def child_linear():
     import torch
     sys.path.insert(0, ROOT)
@@ -74,13 +106,13 @@ def child_linear():
 def main():
     what = sys.argv[1]
     if what.startswith("child_"):
-        return {"child_topk": child_topk, "child_linear": child_linear}[what]()
+        return {"child_topk": child_topk, "child_linear": child_linear, "child_spmm": child_spmm}[what]()
     prefix = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "pmc_" + what)
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     tmp = tempfile.mkdtemp(prefix="mmrec_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     agg = {}   # (kernel, grid) -> {counter: [values]}, plus durations
-    for si, counters in enumerate(SETS):
+    for si, counters in enumerate(SPMM_SETS if what == "spmm" else SETS):
         d = os.path.join(tmp, "set%d" % si)
         cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pm", "--",
                                                              sys.executable, os.path.abspath(__file__), "child_" + what]
@@ -107,7 +139,7 @@ def main():
                 k = (row["Kernel_Name"], grid)
                 agg.setdefault(k, {}).setdefault("duration_ns", []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     shutil.rmtree(tmp, ignore_errors=True)
-    want = ("filter_", "linear_", "gemm64", "slab_reduce", "select_topk", "score_gemm")
+    want = ("spmm_",) if what == "spmm" else ("filter_", "linear_", "gemm64", "slab_reduce", "select_topk", "score_gemm")
     out, lines = {}, []
     for (name, grid), cs in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("duration_ns", [0]))):
         if not any(w in name for w in want):

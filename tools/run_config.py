@@ -48,44 +48,30 @@ CONFIGS = {
 }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=sorted(CONFIGS))
-    ap.add_argument("--epochs", type=int, default=3)
-    ap.add_argument("--device-neg-sampling", action="store_true")
-    ap.add_argument("--graph-step", action="store_true", help="replay the training step as a hipGraph (every model that does not opt out)")
-    ap.add_argument("--no-prefetch", action="store_true", help="row-lazy Adam: catch-up on the main stream (A/B of lazy_prefetch)")
-    ap.add_argument("--eager", action="store_true", help="never replay (default: the plugins that declare graph_capturable)")
-    ap.add_argument("--dense-adam", action="store_true", help="force the dense fused Adam on the trainable feature tables "
-                                                               "(FREEDOM, BM3 default to the row-lazy exact Adam)")
-    args = ap.parse_args()
-    model_name, ds, hyper = CONFIGS[args.config]
-    root = tempfile.mkdtemp(prefix="mmrec_%s_" % ds)
+def setup(name, cd_extra=None, epochs=3, root=None):
+    """dataset on disk (synthetic, the named shape) -> Config -> loaders -> model; returns (config, train, valid, test, model, root)"""
+    model_name, ds, hyper = CONFIGS[name]
+    fresh = root is None
+    root = root or tempfile.mkdtemp(prefix="mmrec_%s_" % ds)
     t0 = time.time()
-    nu, ni, ne = synth.write_dataset(root, ds, seed=0)
-    print("[%s] synthetic %s-shaped data: %d users, %d items, %d interactions (%.1fs)" %
-          (args.config, ds, nu, ni, ne, time.time() - t0), flush=True)
-    if model_name in ("DualGNN", "DRAGON"):          # the user co-occurrence file these two load
+    if fresh:
+        nu, ni, ne = synth.write_dataset(root, ds, seed=0)
+        print("[%s] synthetic %s-shaped data: %d users, %d items, %d interactions (%.1fs)" %
+              (name, ds, nu, ni, ne, time.time() - t0), flush=True)
+    if fresh and model_name in ("DualGNN", "DRAGON"):          # the user co-occurrence file these two load
         from mmrec_amd.utils.user_graph import write_user_graph_file
         t0 = time.time()
         write_user_graph_file(os.path.join(root, ds, ds + ".inter"), os.path.join(root, ds, "user_graph_dict.npy"))
-        print("[%s] user_graph_dict.npy in %.1fs" % (args.config, time.time() - t0), flush=True)
-    if model_name == "DAMRS":                        # its item graph: nothing in the reference writes one
+        print("[%s] user_graph_dict.npy in %.1fs" % (name, time.time() - t0), flush=True)
+    if fresh and model_name == "DAMRS":                        # its item graph: nothing in the reference writes one
         from mmrec_amd.utils.user_graph import write_item_graph_file
         write_item_graph_file(os.path.join(root, ds, ds + ".inter"), os.path.join(root, ds, "item_graph_dict_2.npy"))
-    from mmrec_amd.common.trainer import Trainer
     from mmrec_amd.utils.configurator import Config
     from mmrec_amd.utils.dataloader import EvalDataLoader, TrainDataLoader
     from mmrec_amd.utils.dataset import RecDataset
     from mmrec_amd.utils.utils import eval_batch_size, get_model, init_seed
-    cd = dict(hyper, gpu_id=0, use_gpu=True, data_path=root + "/", epochs=args.epochs,
-              save_recommended_topk=False, device_neg_sampling=args.device_neg_sampling)
-    if args.graph_step or args.eager:
-        cd['hip_graph_step'] = bool(args.graph_step)       # default: 'auto' (overall.yaml)
-    if args.no_prefetch:
-        cd['lazy_prefetch'] = False
-    if args.dense_adam:
-        cd['lazy_feature_adam'] = False
+    cd = dict(hyper, gpu_id=0, use_gpu=True, data_path=root + "/", epochs=epochs, save_recommended_topk=False)
+    cd.update(cd_extra or {})
     config = Config(model_name, ds, cd)
     for k, v in cd.items():
         config[k] = v
@@ -102,8 +88,34 @@ def main():
     t0 = time.time()
     model = get_model(model_name)(config, train_data).to(config["device"])
     torch.cuda.synchronize()
-    print("[%s] model %s built in %.2fs (%d parameters)" % (args.config, model_name, time.time() - t0,
+    print("[%s] model %s built in %.2fs (%d parameters)" % (name, model_name, time.time() - t0,
                                                             sum(p.numel() for p in model.parameters())), flush=True)
+    return config, train_data, valid_data, test_data, model, root
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=sorted(CONFIGS))
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--device-neg-sampling", action="store_true")
+    ap.add_argument("--graph-step", action="store_true", help="replay the training step as a hipGraph (every model that does not opt out)")
+    ap.add_argument("--no-prefetch", action="store_true", help="row-lazy Adam: catch-up on the main stream (A/B of lazy_prefetch)")
+    ap.add_argument("--eager", action="store_true", help="never replay (default: the plugins that declare graph_capturable)")
+    ap.add_argument("--dense-adam", action="store_true", help="force the dense fused Adam on the trainable feature tables "
+                                                               "(FREEDOM, BM3 default to the row-lazy exact Adam)")
+    ap.add_argument("--deterministic", action="store_true", help="hip_deterministic: position-ordered gradient scatters")
+    args = ap.parse_args()
+    cd = dict(device_neg_sampling=args.device_neg_sampling)
+    if args.graph_step or args.eager:
+        cd['hip_graph_step'] = bool(args.graph_step)       # default: 'auto' (overall.yaml)
+    if args.no_prefetch:
+        cd['lazy_prefetch'] = False
+    if args.dense_adam:
+        cd['lazy_feature_adam'] = False
+    if args.deterministic:
+        cd['hip_deterministic'] = True
+    config, train_data, valid_data, test_data, model, _ = setup(args.config, cd, args.epochs)
+    from mmrec_amd.common.trainer import Trainer
     trainer = Trainer(config, model)
     n_eval = valid_data.pr_end + test_data.pr_end
     for epoch in range(args.epochs):
