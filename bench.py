@@ -47,18 +47,27 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 N_LAYERS = 3
+DSLICE_WORLDS = (1, 2, 4, 8)   # 64 / world = 64, 32, 16, 8 columns per rank (mmrec_spmm_csr_f32's slice widths)
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def alg_bytes(nnz, n_rows):
-    return 264 * nnz + 260 * n_rows
+def alg_bytes(nnz, n_rows, d=64):
+    """SURVEY.md 8(d) gather model: 4 col + 4 val + one X row per nonzero, 4 rowptr + one Y row per output row (d = 64: 264 / 260)"""
+    return (8 + 4 * d) * nnz + (4 + 4 * d) * n_rows
 
 
-def alg_compulsory_bytes(nnz, n_rows):
-    return 8 * nnz + 516 * n_rows          # colidx + vals once, rowptr + one read of X and one write of Y per row
+def alg_compulsory_bytes(nnz, n_rows, d=64):
+    return 8 * nnz + (4 + 8 * d) * n_rows  # colidx + vals once, rowptr + one read of X and one write of Y per row
+
+
+def alg_line_bytes(nnz, n_rows, d=64):
+    """what the fabric moves at best for RANDOM gathers: every L2 miss is a 128-B request (profiles/r04_spmm_pmc.txt:
+    TCC_EA0_RDREQ_32B = 0), so a gathered row slice of 4 d < 128 bytes still costs a whole line"""
+    line = max(128, 4 * d)
+    return (8 + line) * nnz + (4 + 4 * d) * n_rows
 
 
 def build_c5(dev, rank, world, layout, multi, n_chunks=None):
@@ -68,7 +77,7 @@ def build_c5(dev, rank, world, layout, multi, n_chunks=None):
     nu, ni, eu, ei = synth.shaped_edges("c5", seed=0)
     r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
     log("c5 graph generated on host in %.1fs (nnz %d)" % (time.time() - t, r.shape[0]))
-    if not multi:
+    if not multi or layout == "dslice":      # the whole graph on every rank (dslice: a rank owns 64 / world COLUMNS of every table)
         sh = BipartiteSharding(nu, ni, world)
         g = hip_ops.CsrGraph.from_coo_device(
             torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
@@ -438,14 +447,8 @@ def extra_baby(dev):
                 "baby": {"n": ni, "F": 4096, "fwd_us": dt * 1e6, "fwd_tflops": out["baby_linear4096_fwd_tflops"],
                          "fwd_frac": out["baby_linear4096_fwd_frac_mfma_f32"], "x_bytes_streamed": 4.0 * ni * 4096,
                          "x_gbs": 4.0 * ni * 4096 / dt / 1e9}}
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma_pmc.json")))
-            proj["mfma_util_counters"] = {k: {"MfmaUtil_busy_cu": v.get("MfmaUtil_busy_cu"), "duration_us": v.get("duration_ns", 0) / 1e3}
-                                          for k, v in pj.items() if v.get("MfmaUtil_busy_cu")}
-            proj["counters_source"] = "profiles/r03_mfma_pmc.json (committed profile of these kernels, not measured in this run)"
-        except Exception:
-            proj["mfma_util_counters"] = None
         out["projection_roofline"] = proj
+        out["_projection_items"] = ni            # (the counters are collected at the end: a child process under rocprofv3)
     # forward + backward (dW, db, dX) of the projection, as FREEDOM / BM3 run it every batch
     Xg, Wg, bg = X.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
     G = torch.rand(ni, 64, device=dev, generator=gen) - 0.5
@@ -474,9 +477,22 @@ def extra_baby(dev):
 
 
 def pmc_child(path):
-    """rocprofv3 child: a few launches of mmrec_spmm_csr_f32 on the graph the parent saved, nothing else."""
+    """rocprofv3 child: a few launches of mmrec_spmm_csr_f32 on the graph the parent saved, nothing else
+    (`linear:<n>`: a few forward + backward passes of the 4096 -> 64 projection over n items instead)."""
     from mmrec_amd import hip_ops
     dev = torch.device("cuda", 0)
+    if path.startswith("linear:"):
+        n = int(path.split(":")[1])
+        gen = torch.Generator(device=dev).manual_seed(0)
+        X = torch.rand(n, 4096, device=dev, generator=gen).requires_grad_()
+        W = (torch.rand(64, 4096, device=dev, generator=gen) - 0.5).requires_grad_()
+        b = torch.zeros(64, device=dev, requires_grad=True)
+        G = torch.rand(n, 64, device=dev, generator=gen) - 0.5
+        for _ in range(4):
+            X.grad = W.grad = b.grad = None
+            hip_ops.linear(X, W, b).backward(G)
+        torch.cuda.synchronize()
+        return
     z = np.load(path)
     n = int(z["n"])
     g = hip_ops.CsrGraph(torch.from_numpy(z["rowptr"]).to(dev), torch.from_numpy(z["colidx"]).to(dev),
@@ -539,6 +555,121 @@ def measure_traffic(g, n_nodes):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_mfma(n_items):
+    """MFMA-pipe counters of the projection kernels IN THIS RUN (north_star: "rocprof MFMA utilisation reported"): the
+    forward / dW / dX kernels of a 4096 -> 64 projection over `n_items` rows in a child process under
+    `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES` (one pass, its own run).
+    MfmaUtil_busy_cu = MFMA busy cycles / (4 SIMDs x busy CU cycles); None when rocprofv3 is not usable here."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mmrec_pmc_", dir="/tmp")
+    try:
+        d = os.path.join(tmp, "mfma")
+        cmd = [exe, "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "--output-format", "csv",
+               "-d", d, "-o", "pm", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "linear:%d" % n_items]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=100)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log("rocprofv3 MFMA pass failed (rc %d): %s" % (r.returncode, r.stderr[-300:]))
+            return None
+        per = {}          # kernel -> dispatch -> counter -> value (a dispatch has one row per counter and XCD: summed)
+        for row in csv.DictReader(open(files[0])):
+            k = row["Kernel_Name"]
+            if "linear_" not in k and "slab_reduce" not in k:
+                continue
+            short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+            cs = per.setdefault(short, {}).setdefault(row.get("Dispatch_Id", ""), {})
+            cs[row["Counter_Name"]] = cs.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        dur = {}
+        for tf in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for row in csv.DictReader(open(tf)):
+                k = row["Kernel_Name"]
+                if "linear_" in k or "slab_reduce" in k:
+                    short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+                    dur.setdefault(short, []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+        out = {}
+        for k, disp in per.items():
+            mf = np.mean([c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for c in disp.values()])
+            cu = np.mean([c.get("SQ_BUSY_CU_CYCLES", 0.0) for c in disp.values()])
+            if cu > 0 and mf > 0:
+                out[k] = {"MfmaUtil_busy_cu": float(mf / (4.0 * cu)), "calls": len(disp),
+                          "duration_us": float(np.mean(dur[k])) / 1e3 if k in dur else None}
+        return out or None
+    except Exception as ex:
+        log("in-run MFMA counter collection failed: %r" % (ex,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def time_spmm(g, x, reps=20):
+    from mmrec_amd import hip_ops
+    y = torch.empty(g.n_rows, x.shape[1], device=x.device)
+    for _ in range(3):
+        hip_ops.spmm_raw(g, x, Y=y)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        hip_ops.spmm_raw(g, x, Y=y)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def dslice_projection(dev, g, n_nodes, ms64):
+    """What the FEATURE-SLICED multi-GPU layout costs, measured on THIS one GPU (round-3 review, item 2): a rank of a P-GPU
+    run owns 64 / P columns of every table and the whole graph, and nothing crosses xGMI inside the propagation -- so the
+    time of ONE slice's layer here IS the P-GPU per-layer time of the layout, and ms(d = 64) / ms(d = 64 / P) its strong
+    scaling.  Next to it: what the row-sharded layouts can reach at this size by their exchange volume."""
+    gen = torch.Generator(device=dev).manual_seed(0)
+    out = {"ms_per_layer_d64": ms64, "ms_per_layer_one_slice": {}, "implied_speedup": {}, "slice_frac_8d": {},
+           "slice_frac_line_model": {}}
+    for P in (2, 4, 8):
+        d = 64 // P
+        x = torch.rand(n_nodes, d, device=dev, generator=gen) - 0.5
+        ms = time_spmm(g, x)
+        out["ms_per_layer_one_slice"][str(d)] = ms
+        out["implied_speedup"][str(P)] = ms64 / ms
+        out["slice_frac_8d"][str(d)] = alg_bytes(g.nnz, g.n_rows, d) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["slice_frac_line_model"][str(d)] = alg_line_bytes(g.nnz, g.n_rows, d) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        del x
+    out["row_sharded_predictions_at_8"] = {"allgather": "1.1-1.7 x (336 MB into every rank per layer over 7 xGMI links against "
+                                                        "~0.1 ms of SpMM per rank)", "allreduce": "1.7-2.4 x (224 MB)"}
+    out["what"] = ("one layer of the config-5 graph (20M nnz, 1.5M rows) on [N, 64 / P] slices through mmrec_spmm_csr_f32, on "
+                   "this GPU; implied_speedup[P] = ms_per_layer_d64 / ms_per_layer_one_slice[64 / P]: the layout's strong "
+                   "scaling at P GPUs (no exchange in the propagation; the slices are all-gathered once per evaluation). "
+                   "slice_frac_line_model: against 128-B fabric requests per gathered row -- what bounds a slice "
+                   "(profiles/r04_spmm_pmc.txt)")
+    return out
+
+
+def c5_train_step_roofline(dev, nu, ni, eu, ei):
+    """The SpMM launches the config-5 FREEDOM step actually runs (freedom.py:128-143,164-177): the 80 %-pruned user-item
+    graph (4M nnz over 1.5M rows: 2.7 per row; four launches per step, forward + backward of two layers) and the item-item
+    kNN graph (10M nnz over 500K rows; two launches) -- ms per launch, SURVEY.md 8(d) bytes / time / 8 TB/s."""
+    from mmrec_amd import hip_ops
+    keep = torch.randperm(eu.shape[0], generator=torch.Generator().manual_seed(0))[:int(eu.shape[0] * 0.2)]
+    pruned = hip_ops.bipartite_graph_from_edges(torch.from_numpy(eu)[keep].to(dev), torch.from_numpy(ei)[keep].to(dev), nu, ni)
+    rng = np.random.default_rng(1)
+    rows = np.repeat(np.arange(ni), 20)
+    mm = hip_ops.CsrGraph.from_coo_host(np.stack([rows, rng.integers(0, ni, rows.shape[0])]),
+                                        np.full(rows.shape[0], 0.05, np.float32), ni, ni, dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    out = {}
+    for name, g, n_x in (("pruned_user_item", pruned, nu + ni), ("item_item_knn", mm, ni)):
+        x = torch.rand(n_x, 64, device=dev, generator=gen) - 0.5
+        ms = time_spmm(g, x)
+        ab = alg_bytes(g.nnz, g.n_rows)
+        out[name] = {"nnz": g.nnz, "rows": g.n_rows, "nnz_per_row": g.nnz / g.n_rows, "ms_per_launch": ms,
+                     "alg_bytes_per_launch": float(ab), "achieved": ab / (ms * 1e-3) / 1e9,
+                     "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del x
+    out["what"] = ("mmrec_spmm_csr_f32, d = 64, on the two graphs of the config-5 training step; frac = (264 B x nnz + 260 B x "
+                   "rows) / ms_per_launch / 8 TB/s (the headline's definition); counters: profiles/r04_spmm_pmc.txt")
+    return out
 
 
 def committed_traffic():
@@ -627,11 +758,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: run the N > 1 code path (process group, sharded blocks, "
                          "collectives) with a single rank")
-    ap.add_argument("--layout", choices=["allgather", "allreduce"], default="allgather",
-                    help="N > 1: 'allgather' (default; north_star's wording) = rows sharded nnz-balanced, blocks "
+    ap.add_argument("--layout", choices=["dslice", "allgather", "allreduce"], default=None,
+                    help="N > 1: 'dslice' (default for 2 / 4 / 8 ranks) = FEATURE-sliced: every rank owns 64 / N columns of "
+                         "every table and the whole graph, Y[:, s] = A X[:, s] needs no exchange for any number of layers, "
+                         "bit-exact vs 1 GPU; 'allgather' (north_star's wording) = rows sharded nnz-balanced, blocks "
                          "all-gathered per layer in chunks under the next chunk's SpMM, bit-exact vs 1 GPU; "
                          "'allreduce' = users sharded / items replicated, item partial sums all-reduced per "
-                         "layer (2/3 of the volume, fp32-rounding-equal)")
+                         "layer (2/3 of the all-gather volume, fp32-rounding-equal)")
     ap.add_argument("--chunks", type=int, default=None, help="row chunks per rank of the allgather layout (default: auto)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group / sharding-plan self-test: no device work, no numbers (runs without a GPU)")
@@ -649,6 +782,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if args.layout is None:     # measured on one GPU (extra.dslice_projection): the feature-sliced layout beats both row-sharded ones
+        args.layout = "dslice" if world in DSLICE_WORLDS else "allgather"
+    if args.layout == "dslice" and world not in DSLICE_WORLDS:
+        raise SystemExit("--layout dslice needs 1, 2, 4 or 8 ranks (64 columns / ranks = a slice width the kernel has)")
     if args.dry_run:
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
@@ -674,7 +811,11 @@ def main():
     sh, g, ublk, iblk, r, c, v = build_c5(dev, rank, world, args.layout, multi, args.chunks)
     nnz_total, n_nodes = int(r.shape[0]), sh.n_users + sh.n_items
     gen = torch.Generator(device=dev).manual_seed(0)   # same seed -> same X0 on every rank
-    X0 = torch.rand(sh.N_pad if multi else n_nodes, 64, device=dev, generator=gen) - 0.5
+    dslice = multi and args.layout == "dslice"
+    d_loc = 64 // world if dslice else 64
+    X0 = torch.rand(sh.N_pad if (multi and not dslice) else n_nodes, 64, device=dev, generator=gen) - 0.5
+    if dslice and d_loc < 64:                           # this rank's columns of the same table
+        X0 = X0[:, rank * d_loc:(rank + 1) * d_loc].contiguous()
     bufs = [torch.empty_like(X0), torch.empty_like(X0)]
     ev = []   # (start, stop) HIP events around every SpMM call in the timed region
     timed = False
@@ -685,12 +826,12 @@ def main():
             s.record()
             hip_ops.spmm_raw(block, X, Y=Y, **ep)
             e.record()
-            ev.append((s, e, block.nnz, block.n_rows))
+            ev.append((s, e, block.nnz, block.n_rows, X.shape[1]))
         else:
             hip_ops.spmm_raw(block, X, Y=Y, **ep)
 
     prop = None
-    if not multi:
+    if not multi or dslice:      # dslice: the same three launches on this rank's columns -- nothing crosses xGMI
         def step():
             cur = X0
             for layer in range(N_LAYERS):
@@ -752,8 +893,8 @@ def main():
     if multi:
         # every rank's own view, gathered NOW (the emitting code may run on a watchdog thread: no collectives there):
         # own wall time per step, mean SpMM call duration, gather-model GB/s of its calls
-        ms = np.array([s_.elapsed_time(e_) for s_, e_, _, _ in timed_events])
-        ab = np.array([alg_bytes(nz, nr) for _, _, nz, nr in timed_events], dtype=np.float64)
+        ms = np.array([s_.elapsed_time(e_) for s_, e_, _, _, _ in timed_events])
+        ab = np.array([alg_bytes(nz, nr, dd) for _, _, nz, nr, dd in timed_events], dtype=np.float64)
         mine = torch.tensor([local_t["own"] / args.steps * 1e3, float(ms.mean()), float(ab.sum() / (ms.sum() * 1e-3) / 1e9),
                              float(len(ms))], device=dev, dtype=torch.float64)
         allr = torch.empty(world * 4, device=dev, dtype=torch.float64)
@@ -827,10 +968,18 @@ def main():
                 "overlap_frac": max(0.0, min(1.0, (t_comp + t_comm - t_tot) / max(min(t_comp, t_comm), 1e-9))),
                 "note_exchange": "per-GPU inbound payload of the per-layer all-gathers (fp32 rows); overlap_frac = share of "
                                  "the shorter of {SpMMs, exchange} that ran hidden under the other"})
-        full = hip_ops.CsrGraph.from_coo_device(
-            torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
-            torch.from_numpy(v).to(dev), n_nodes, n_nodes, symmetric=True)
-        xa = X0[:n_nodes].contiguous()
+        if dslice:
+            dist_extra["columns_per_rank"] = d_loc
+            dist_extra["exchange_bytes_in_per_rank_per_step"] = 0
+            dist_extra["note_exchange"] = ("feature-sliced: every rank runs the whole graph on its own %d columns; no collective "
+                                           "inside the propagation (the slices meet once per evaluation: c5_full_eval)" % d_loc)
+            full = g
+            xa = torch.rand(n_nodes, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) - 0.5
+        else:
+            full = hip_ops.CsrGraph.from_coo_device(
+                torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
+                torch.from_numpy(v).to(dev), n_nodes, n_nodes, symmetric=True)
+            xa = X0[:n_nodes].contiguous()
         xb, xc = torch.empty_like(xa), torch.empty_like(xa)
 
         def rep_step():
@@ -864,12 +1013,24 @@ def main():
             raise RuntimeError("--headline-only")
         ne = nnz_total // 2                       # sym_norm_coo: the first half are the user rows, sorted by (user, item)
         eu_all, ei_all = r[:ne], c[:ne] - sh.n_users
-        E = bufs[(N_LAYERS - 1) % 2] if (not multi or args.layout == "allgather") else None
+        E = bufs[(N_LAYERS - 1) % 2] if (not multi or args.layout in ("allgather", "dslice")) else None
+        if dslice and world > 1:
+            # the ONE exchange of the feature-sliced layout: the ranks' column slices of the final tables -> the full rows the
+            # ranking needs (an all-gather of [N, 64 / P] blocks, then columns interleaved back; once per evaluation)
+            fence()
+            t_x = time.perf_counter()
+            parts = torch.empty(world, n_nodes, d_loc, device=dev)
+            dist.all_gather_into_tensor(parts, E)
+            E = parts.permute(1, 0, 2).reshape(n_nodes, 64).contiguous()
+            del parts
+            fence()
+            dist_extra["eval_table_allgather_ms"] = (time.perf_counter() - t_x) * 1e3
+            dist_extra["eval_table_allgather_bytes_in_per_rank"] = int((world - 1) * n_nodes * d_loc * 4)
         if E is None:
             ge = torch.Generator(device=dev).manual_seed(1)
             Ue = torch.rand(sh.n_users, 64, device=dev, generator=ge) - 0.5
             Ie = torch.rand(sh.n_items, 64, device=dev, generator=ge) - 0.5
-        elif multi:
+        elif multi and not dslice:
             Ue, Ie = (t.contiguous() for t in sh.unpad(E))
         else:
             Ue, Ie = E[:sh.n_users].contiguous(), E[sh.n_users:].contiguous()
@@ -908,35 +1069,46 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
     """rank 0: the ONE JSON line (headline + roofline + companions gathered so far)"""
     dist_extra, c5_eval = state["dist_extra"], state["c5_eval"]
     # roofline of the dominant kernel family (one SpMM call), from the events of this rank
-    call_ms = np.array([s.elapsed_time(e) for s, e, _, _ in ev])
-    call_alg = np.array([alg_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
-    call_min = np.array([alg_compulsory_bytes(nz, nr) for _, _, nz, nr in ev], dtype=np.float64)
+    call_ms = np.array([s.elapsed_time(e) for s, e, _, _, _ in ev])
+    call_alg = np.array([alg_bytes(nz, nr, dd) for _, _, nz, nr, dd in ev], dtype=np.float64)
+    call_min = np.array([alg_compulsory_bytes(nz, nr, dd) for _, _, nz, nr, dd in ev], dtype=np.float64)
+    call_line = np.array([alg_line_bytes(nz, nr, dd) for _, _, nz, nr, dd in ev], dtype=np.float64)
     ms_launch = float(call_ms.mean())
     alg_gbs = float(call_alg.sum() / (call_ms.sum() * 1e-3) / 1e9)
     traffic = None
     if rank == 0 and not multi:
         traffic = (None if args.no_pmc else measure_traffic(g, n_nodes)) or committed_traffic()
+    d_call = int(ev[0][4]) if ev else 64
+    # ONE definition of the headline fraction: SURVEY.md 8(d) -- achieved = algorithmic (gather-model) bytes per launch / mean
+    # launch time, frac = achieved / 8 TB/s.  The counter view (bytes that really cross L2, <= what the fabric can carry)
+    # rides along under its own names.
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "kernel": "mmrec_spmm_csr_f32 (spmm_rows_kernel + long-row chunk/reduce kernels)",
+                "kernel": ("mmrec_spmm_csr_f32 (spmm_rows_kernel + long-row chunk/reduce kernels)" if d_call == 64 else
+                           "mmrec_spmm_csr_f32 on a %d-column feature slice (spmm_narrow_rows_kernel + long-row reduce)" % d_call),
                 "ms_per_launch": ms_launch, "launches_timed": int(len(ev)),
-                "alg_bytes_per_launch": float(call_alg.mean()), "achieved_gather_model": alg_gbs,
-                "frac_gather_model": alg_gbs / HBM_PEAK_GBS,
-                # the SURVEY.md 8(d) figure under its own name: (264 B x nnz + 260 B x rows) / mean launch time / 8 TB/s
-                "achieved_8d": alg_gbs, "frac_8d": alg_gbs / HBM_PEAK_GBS,
+                "achieved": alg_gbs, "frac": alg_gbs / HBM_PEAK_GBS,
+                "definition": "SURVEY.md 8(d): achieved = ((8 + 4 d) B x nnz + (4 + 4 d) B x rows) per launch / mean launch "
+                              "duration (HIP events in the timed region), frac = achieved / 8 TB/s; d = %d columns.  Above 1 is "
+                              "possible by this definition (L2 absorbs re-gathered rows): frac_counter_bytes is the <= 1 view" % d_call,
+                "alg_bytes_per_launch": float(call_alg.mean()),
+                "achieved_8d": alg_gbs, "frac_8d": alg_gbs / HBM_PEAK_GBS,           # (round-3 names, kept)
+                "achieved_gather_model": alg_gbs, "frac_gather_model": alg_gbs / HBM_PEAK_GBS,
+                # what the fabric has to move for random gathers: every L2 miss is a 128-B request, whatever the slice width
+                "line_model_bytes_per_launch": float(call_line.mean()),
+                "frac_line_model": float(call_line.sum() / (call_ms.sum() * 1e-3) / 1e9) / HBM_PEAK_GBS,
                 "compulsory_bytes_per_launch": float(call_min.mean()),
                 "frac_compulsory": float(call_min.sum() / (call_ms.sum() * 1e-3) / 1e9) / HBM_PEAK_GBS}
-    if traffic is not None:      # headline: what the launch really moves past L2 (<= the fabric can carry: <= 1)
-        roofline.update({"achieved": traffic["bytes"] / (ms_launch * 1e-3) / 1e9,
-                         "frac": traffic["bytes"] / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic["bytes"], "traffic_fetch_bytes": traffic["fetch_bytes"],
+    if traffic is not None:      # what the launch really moves past L2 (<= the fabric can carry: <= 1)
+        roofline.update({"traffic": traffic["bytes"], "traffic_fetch_bytes": traffic["fetch_bytes"],
                          "traffic_write_bytes": traffic["write_bytes"], "l2_hit_rate": traffic["l2_hit_rate"],
                          "traffic_source": traffic["source"],
-                         "definition": "achieved = (FETCH_SIZE x2 + WRITE_SIZE) per launch / ms_per_launch: bytes crossing "
-                                       "L2 -> Infinity Fabric (Infinity-Cache hits included); gather model and compulsory "
-                                       "bound alongside"})
-    else:                        # N > 1 ranks / no profiler and no committed profile: the gather model only
-        roofline.update({"achieved": alg_gbs, "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "definition": "gather model (no counters available in this run)"})
+                         "achieved_counter_bytes": traffic["bytes"] / (ms_launch * 1e-3) / 1e9,
+                         "frac_counter_bytes": traffic["bytes"] / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_over_algorithmic": traffic["bytes"] / float(call_alg.mean()),
+                         "definition_counter_bytes": "(FETCH_SIZE x2 + WRITE_SIZE) per launch / ms_per_launch: bytes crossing "
+                                                     "L2 -> Infinity Fabric (Infinity-Cache hits included)"})
+    else:                        # N > 1 ranks / no profiler and no committed profile
+        roofline.update({"traffic": None})
 
     if rank == 0:
         line = {
@@ -949,7 +1121,9 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                                    "LightGCN-style 3-layer propagation, d=64",
                        "layers": N_LAYERS, "nnz": nnz_total, "rows": n_nodes,
                        "parallelism": "single GPU" if not multi else
-                       ("users sharded x%d, items replicated, RCCL all-reduce of item sums per layer" % world
+                       ("feature-sliced x%d: every rank owns %d of the 64 columns of every table and the whole graph; no "
+                        "exchange in the propagation" % (world, 64 // world) if args.layout == "dslice" else
+                        "users sharded x%d, items replicated, RCCL all-reduce of item sums per layer" % world
                         if args.layout == "allreduce" else
                         "rows sharded x%d (nnz-balanced, %d chunks/rank), RCCL all-gather per layer" % (world, sh.n_chunks))},
             "roofline": roofline,
@@ -969,6 +1143,35 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                 line["extra"]["c5_propagate_fwd_bwd"] = c5_fwd_bwd(dev, g, n_nodes, nnz_total)
             except Exception as ex:
                 line["extra"]["c5_propagate_fwd_bwd"] = {"error": repr(ex)}
+            try:
+                line["extra"]["dslice_projection"] = dslice_projection(dev, g, n_nodes, ms_launch)
+            except Exception as ex:
+                line["extra"]["dslice_projection"] = {"error": repr(ex)}
+            # the projection's MFMA counters, IN THIS RUN (a child process under rocprofv3 --pmc, its own pass)
+            pr = line["extra"].get("projection_roofline") if isinstance(line["extra"], dict) else None
+            if pr is not None:
+                n_proj = line["extra"].pop("_projection_items", None)
+                got = None if (args.no_pmc or not n_proj) else measure_mfma(n_proj)
+                if got:
+                    pr["mfma_util_counters"] = got
+                    pr["counters_source"] = ("in-run: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES, one "
+                                             "pass, 4 forward + backward calls at %d items; MfmaUtil_busy_cu = MFMA busy cycles / "
+                                             "(4 SIMDs x busy CU cycles)" % n_proj)
+                else:
+                    try:
+                        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma_pmc.json")))
+                        pr["mfma_util_counters"] = {k: {"MfmaUtil_busy_cu": v.get("MfmaUtil_busy_cu"),
+                                                        "duration_us": v.get("duration_ns", 0) / 1e3}
+                                                    for k, v in pj.items() if v.get("MfmaUtil_busy_cu")}
+                        pr["counters_source"] = "profiles/r03_mfma_pmc.json (a committed profile of these kernels, NOT measured in this run)"
+                    except Exception:
+                        pr["mfma_util_counters"] = None
+            try:
+                ne = nnz_total // 2
+                line["extra"]["c5_train_step_roofline"] = c5_train_step_roofline(dev, sh.n_users, sh.n_items, r[:ne],
+                                                                                 c[:ne] - sh.n_users)
+            except Exception as ex:
+                line["extra"]["c5_train_step_roofline"] = {"error": repr(ex)}
         if multi:
             line["extra"] = dist_extra
             line["per_rank"] = state.get("per_rank")

@@ -52,6 +52,11 @@ def main():
     cols = rng.integers(0, ni, rows.shape[0])
     graphs["c5_item_item_10M"] = (hip_ops.CsrGraph.from_coo_host(np.stack([rows, cols]),
                                                                  np.full(rows.shape[0], 0.05, np.float32), ni, ni, dev), ni)
+    # the same row structure as the full graph, but every column id folded into a 65,536-row window: the X slice a launch
+    # gathers from is 2 MB at d = 8 -- L2 resident.  What a slice launch would take if its gathers hit L2 (the ceiling of
+    # any scheme that makes them, e.g. all rows walking the column space in step).
+    c_fold = (c % 65536).astype(c.dtype)
+    graphs["c5_full_20M_cols_folded_to_64K"] = (hip_ops.CsrGraph.from_coo_host(np.stack([r, c_fold]), v, n, n, dev), n)
     out = {}
     for name, (g, n_x) in graphs.items():
         t = {d: time_layer(g, n_x, d, args.reps) for d in (64, 32, 16, 8)}
