@@ -1019,9 +1019,9 @@ def main():
             # ranking needs (an all-gather of [N, 64 / P] blocks, then columns interleaved back; once per evaluation)
             fence()
             t_x = time.perf_counter()
-            parts = torch.empty(world, n_nodes, d_loc, device=dev)
+            parts = torch.empty(world * n_nodes, d_loc, device=dev)                  # rank-major row blocks
             dist.all_gather_into_tensor(parts, E)
-            E = parts.permute(1, 0, 2).reshape(n_nodes, 64).contiguous()
+            E = parts.view(world, n_nodes, d_loc).permute(1, 0, 2).reshape(n_nodes, 64).contiguous()
             del parts
             fence()
             dist_extra["eval_table_allgather_ms"] = (time.perf_counter() - t_x) * 1e3

@@ -211,8 +211,8 @@ def _local_spmm(blk, X, Y, **ep):
     return hip_ops.spmm_raw(blk, X, Y=Y, **ep)
 
 
-class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
-    """FREEDOM over `n_gpus` processes (torch.distributed initialised by the launcher; utils/quick_start.py does it from
+class RowShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
+    """FREEDOM over `n_gpus` processes, ROWS of the graphs sharded (config `dist_layout: rows`) (torch.distributed initialised by the launcher; utils/quick_start.py does it from
     the torchrun environment).  What is sharded and what is replicated:
 
       * user-item graph (and its per-epoch pruned version): ROWS sharded, nnz-balanced (dist.BipartiteSharding); every
@@ -236,7 +236,7 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         from mmrec_amd.dist import BipartiteSharding, ShardedPropagator, ShardedSquareMatrix, space_blocks
         from mmrec_amd.graph import sym_norm_coo, unique_edges
         if not tdist.is_initialized():
-            raise RuntimeError('ShardedFREEDOM needs torch.distributed (launch with torchrun; config n_gpus)')
+            raise RuntimeError('RowShardedFREEDOM needs torch.distributed (launch with torchrun; config n_gpus)')
         self.group = None
         self.rank, self.world = tdist.get_rank(), tdist.get_world_size()
         self.force = bool(config['dist_force_collectives'])     # testing aid: run the collectives at world size 1 too
@@ -451,3 +451,254 @@ class ShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
                 parts = [buf]
             out[name + '.weight'] = torch.cat([p[:int(cuts[r + 1] - cuts[r])] for r, p in enumerate(parts)], 0)
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# n_gpus > 1, FEATURE-sliced (config `dist_layout: dslice`; the default at 2 / 4 / 8 ranks)
+# ------------------------------------------------------------------------------------------------------------------
+class _AllReduceSum(torch.autograd.Function):
+    """sum over ranks of rank-local partial results whose CONSUMER is replicated (every rank computes the same loss from the
+    sum): forward all-reduce; the incoming gradient is the same on every rank and is each rank's own partial's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, group, multi):
+        out = x.contiguous().clone()
+        if multi:
+            import torch.distributed as tdist
+            tdist.all_reduce(out, op=tdist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+class _TakeColumns(torch.autograd.Function):
+    """this rank's column slice of a REPLICATED [B, d] matrix whose producer needs the gradient of ALL columns (the owner of
+    a projected feature row back-propagates through its whole row): backward places the rank's [B, d / P] gradient at its
+    columns and sums over the ranks -- every rank ends with the full [B, d] gradient."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi, group, multi):
+        ctx.lo, ctx.hi, ctx.width, ctx.group, ctx.multi = lo, hi, x.shape[1], group, multi
+        return x[:, lo:hi].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        full = g.new_zeros(g.shape[0], ctx.width)
+        full[:, ctx.lo:ctx.hi] = g
+        if ctx.multi:
+            import torch.distributed as tdist
+            tdist.all_reduce(full, op=tdist.ReduceOp.SUM, group=ctx.group)
+        return full, None, None, None, None
+
+
+def sliced_bpr_losses(ua_s, users, terms, group, multi):
+    """FREEDOM.bpr_loss (freedom.py:180-187) per term on COLUMN SLICES: every rank holds d / P columns of the user table and of
+    each term's table, <u, p> - <u, n> is the sum over ranks of the slices' partial dot products -- ONE all-reduce of
+    [terms, 2, B] floats per step (48 KB at B = 2048) -- and -mean(logsigmoid(.)) is computed replicated.  Backward needs no
+    collective: d loss / d score is the same on every rank and each rank differentiates its own columns."""
+    u = ua_s[users]
+    dots = torch.stack([torch.stack(((u * t[p]).sum(1), (u * t[n]).sum(1))) for t, p, n in terms])
+    dots = _AllReduceSum.apply(dots, group, multi)
+    return tuple(-torch.nn.functional.logsigmoid(dots[j, 0] - dots[j, 1]).mean() for j in range(len(terms)))
+
+
+class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
+    """FREEDOM over `n_gpus` = P in {2, 4, 8} processes, the FEATURE dimension sliced:
+
+      * every rank holds the WHOLE user-item graph (and its per-epoch pruned version) and the whole item-item graph, and
+        d / P = 32 / 16 / 8 COLUMNS of the id embedding tables, their gradients and their Adam state.  `Y[:, s] = A X[:, s]`:
+        all propagation layers, forward and backward, are local launches of mmrec_spmm_csr_f32 on the slice
+        (csrc/spmm_narrow.hip) -- NOTHING crosses xGMI there, and a column's values are the single-GPU kernel's bit for bit
+        (the row-sharded layout moves 224-336 MB into every rank per layer at config 5 against 0.1 ms of SpMM);
+      * the three BPR terms need <u, p> - <u, n> over all 64 columns: one all-reduce of the [3, 2, B] partial dot products;
+      * raw feature tables and their Adam state: item-sharded as in RowShardedFREEDOM (owner-computed projections of the
+        batch rows, exchanged as [2B, 64] rows; the owners get the full-width gradient back through one all-reduce);
+      * evaluation: the slices of the final tables are all-gathered ONCE per evaluation into replicated [N, 64] tables, then
+        every rank ranks its share of the users (no exchange in the scoring).
+    Parameter names are FREEDOM's; `user_embedding.weight` / `item_id_embedding.weight` hold the rank's columns,
+    `image_embedding.weight` / `text_embedding.weight` the rank's rows (`gather_tables()` rebuilds the full tensors)."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        import torch.distributed as tdist
+        if not tdist.is_initialized():
+            raise RuntimeError('SlicedFREEDOM needs torch.distributed (launch with torchrun; config n_gpus)')
+        self.group = None
+        self.rank, self.world = tdist.get_rank(), tdist.get_world_size()
+        self.force = bool(config['dist_force_collectives'])
+        self.multi = self.world > 1 or self.force
+        self.embedding_dim = config['embedding_size']
+        if self.embedding_dim % self.world or self.embedding_dim // self.world not in (8, 16, 32, 64):
+            raise ValueError('dist_layout dslice: embedding_size %d over %d ranks is not a slice width the SpMM kernel has '
+                             '(8, 16, 32 columns per rank); use dist_layout: rows' % (self.embedding_dim, self.world))
+        self.d_loc = self.embedding_dim // self.world
+        self.col_lo, self.col_hi = self.rank * self.d_loc, (self.rank + 1) * self.d_loc
+        self.feat_embed_dim = config['feat_embed_dim']
+        self.knn_k = config['knn_k']
+        self.n_layers = config['n_mm_layers']
+        self.n_ui_layers = config['n_ui_layers']
+        self.reg_weight = config['reg_weight']
+        self.mm_image_weight = config['mm_image_weight']
+        self.dropout = config['dropout']
+        n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
+        self.lazy_feature_adam = lazy_adam_enabled(config, n_feat)
+        self.graph_capturable = False
+        nu, ni = self.n_users, self.n_items
+        self.n_nodes = nu + ni
+
+        self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
+        self.norm_adj = norm_adj_graph(self.interaction_matrix, nu, ni, self.device)
+        self.masked_adj = None
+        rows = torch.from_numpy(self.interaction_matrix.row.astype(np.int64))
+        cols = torch.from_numpy(self.interaction_matrix.col.astype(np.int64))
+        self.edge_indices = torch.stack([rows, cols]).to(self.device)
+        self.edge_values = hip_ops.edge_norm_values(self.edge_indices[0].contiguous(), self.edge_indices[1].contiguous(),
+                                                    nu, ni)
+
+        # parameters in FREEDOM's construction order on FULL tables (same generator consumption -> the single-process
+        # model's initial values), then this rank's columns
+        full_u, full_i = nn.Embedding(nu, self.embedding_dim).weight.data, nn.Embedding(ni, self.embedding_dim).weight.data
+        nn.init.xavier_uniform_(full_u)
+        nn.init.xavier_uniform_(full_i)
+        cols = slice(self.col_lo, self.col_hi)
+        self.user_embedding = nn.Embedding.from_pretrained(full_u[:, cols].contiguous(), freeze=False)
+        self.item_id_embedding = nn.Embedding.from_pretrained(full_i[:, cols].contiguous(), freeze=False)
+        del full_u, full_i
+        per = -(-ni // self.world)
+        self.item_lo, self.item_hi = min(self.rank * per, ni), min((self.rank + 1) * per, ni)
+        self.item_cuts = [min(r * per, ni) for r in range(self.world + 1)]
+        table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
+
+        def local_rows(feat):
+            rows_ = feat[self.item_lo:self.item_hi]
+            return rows_.clone() if rows_.shape[0] else feat.new_zeros(1, feat.shape[1])   # an empty block owns nothing
+        if self.v_feat is not None:
+            self.image_embedding = table.from_pretrained(local_rows(self.v_feat), freeze=False)
+            self.image_trs = nn.Linear(self.v_feat.shape[1], self.feat_embed_dim)
+        if self.t_feat is not None:
+            self.text_embedding = table.from_pretrained(local_rows(self.t_feat), freeze=False)
+            self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
+        mm = load_or_build_mm_coo(config, self.v_feat, self.t_feat, self.knn_k, self.mm_image_weight, ni,
+                                  write=self.rank == 0)
+        self.mm_adj = sparse_coo_to_graph(mm, self.device)
+        self.mm_adj.transpose()
+        self.has_text, self.has_image = self.t_feat is not None, self.v_feat is not None
+        if config['dist_keep_full_features'] is not True:
+            self.v_feat = None if self.v_feat is None else self.v_feat[:0]
+            self.t_feat = None if self.t_feat is None else self.t_feat[:0]
+
+    def pre_epoch_processing(self):
+        import torch.distributed as tdist
+        if self.dropout <= .0:
+            self.masked_adj = self.norm_adj
+            return
+        keep_len = int(self.edge_values.size(0) * (1. - self.dropout))
+        keep = torch.multinomial(self.edge_values, keep_len)     # every rank draws (generators stay aligned) ...
+        if self.world > 1:                                        # ... and rank 0's draw is the one everybody uses
+            tdist.broadcast(keep, src=0, group=self.group)
+        self.set_kept_edges(keep)
+
+    def set_kept_edges(self, keep_idx):
+        kept = self.edge_indices[:, keep_idx]
+        self.masked_adj = hip_ops.bipartite_graph_from_edges(kept[0].contiguous(), kept[1].contiguous(),
+                                                             self.n_users, self.n_items)
+
+    def forward(self, adj):
+        """this rank's COLUMNS of (user_all, item_all): FREEDOM.forward on [*, d / P] slices, no collective"""
+        u_g, i_g = hip_ops.lightgcn_mean_parts(adj, (self.user_embedding.weight, self.item_id_embedding.weight), self.n_ui_layers)
+        h = self.item_id_embedding.weight
+        if self.n_layers == 0:
+            return u_g, i_g + h
+        for _ in range(self.n_layers - 1):
+            h = hip_ops.spmm(self.mm_adj, h)
+        return u_g, hip_ops.spmm(self.mm_adj, h, Z=i_g)
+
+    def _all_columns(self, t):
+        """[n, d / P] slices of all ranks -> the replicated [n, d] table (the layout's one bulk exchange: per evaluation)"""
+        import torch.distributed as tdist
+        if self.world == 1:
+            return t
+        parts = torch.empty(self.world * t.shape[0], t.shape[1], dtype=t.dtype, device=t.device)      # rank-major row blocks
+        tdist.all_gather_into_tensor(parts, t.contiguous(), group=self.group)
+        return parts.view(self.world, t.shape[0], t.shape[1]).permute(1, 0, 2).reshape(t.shape[0], -1).contiguous()
+
+    def eval_embeddings(self):
+        u, i = self.forward(self.norm_adj)
+        return self._all_columns(u), self._all_columns(i)
+
+    def _owned_projection(self, emb, trs, rows):
+        """this rank's columns of the [2B, 64] projected feature rows of the batch items, each row computed by its owner"""
+        from mmrec_amd.dist import exchange_owned_rows
+        owned = (rows >= self.item_lo) & (rows < self.item_hi)
+        if self.lazy_feature_adam:        # slots of other ranks' items: -1 = "no row" (no catch-up, no gradient, no step)
+            emb.allow_missing = True
+            feats = emb.rows(torch.where(owned, rows - self.item_lo, torch.full_like(rows, -1)))
+        else:
+            feats = emb.weight[torch.where(owned, rows - self.item_lo, torch.zeros_like(rows))]
+        w, b = _SumGradOverRanks.apply(trs.weight, self.group), _SumGradOverRanks.apply(trs.bias, self.group)
+        full = exchange_owned_rows(hip_ops.linear(feats, w, b), owned, group=self.group, multi=self.multi)
+        return _TakeColumns.apply(full, self.col_lo, self.col_hi, self.group, self.multi)
+
+    def calculate_loss(self, interaction):
+        users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
+        ua, ia = self.forward(self.masked_adj)
+        rows = torch.cat((pos_items, neg_items))
+        b = pos_items.shape[0]
+        lp = torch.arange(b, device=rows.device)
+        ln = lp + b
+        terms = [(ia, pos_items, neg_items)]
+        if self.has_text:
+            terms.append((self._owned_projection(self.text_embedding, self.text_trs, rows), lp, ln))
+        if self.has_image:
+            terms.append((self._owned_projection(self.image_embedding, self.image_trs, rows), lp, ln))
+        return _combine(sliced_bpr_losses(ua, users, terms, self.group, self.multi), self.has_text, self.reg_weight)
+
+    full_sort_topk = RowShardedFREEDOM.full_sort_topk        # users sharded over the ranks, replicated item table
+
+    @torch.no_grad()
+    def gather_tables(self):
+        """-> {name: full tensor}: the id tables re-assembled from the ranks' columns, the feature tables from their rows
+        (collective; for export / state_dict)"""
+        import torch.distributed as tdist
+        from mmrec_amd.common.lazy_rows import flush_lazy_tables
+        flush_lazy_tables(self)
+        out = {'user_embedding.weight': self._all_columns(self.user_embedding.weight.detach()),
+               'item_id_embedding.weight': self._all_columns(self.item_id_embedding.weight.detach())}
+        cuts = self.item_cuts
+        for name in ('image_embedding', 'text_embedding'):
+            if not hasattr(self, name):
+                continue
+            w = getattr(self, name).weight
+            cap = max(cuts[r + 1] - cuts[r] for r in range(self.world))
+            buf = w.new_zeros(max(cap, 1), w.shape[1])
+            n = self.item_hi - self.item_lo
+            buf[:n] = w[:n]
+            parts = [torch.empty_like(buf) for _ in range(self.world)]
+            if self.world > 1:
+                tdist.all_gather(parts, buf, group=self.group)
+            else:
+                parts = [buf]
+            out[name + '.weight'] = torch.cat([p[:cuts[r + 1] - cuts[r]] for r, p in enumerate(parts)], 0)
+        return out
+
+    gather_feature_tables = gather_tables
+
+
+def ShardedFREEDOM(config, dataset):
+    """what `get_model('FREEDOM', sharded=True)` hands to quick_start (config `n_gpus` > 1): the layout named by the new key
+    `dist_layout` -- 'dslice' (feature-sliced, no exchange in the propagation: SlicedFREEDOM), 'rows' (row-sharded graphs,
+    one all-gather per layer: RowShardedFREEDOM, north_star's wording), or 'auto' / unset: dslice where the embedding width
+    divides into slices the kernel has (2 / 4 / 8 ranks at d = 64), rows otherwise.  One GPU measures why
+    (bench.py extra.dslice_projection): a slice's layer takes 0.29-0.39 ms at config 5 against 0.78 ms on one GPU, the
+    row-sharded layouts are bound by 224-336 MB of exchange per rank and layer."""
+    import torch.distributed as tdist
+    layout = config['dist_layout'] or 'auto'
+    world = tdist.get_world_size() if tdist.is_initialized() else 1
+    if layout == 'auto':
+        d = config['embedding_size']
+        layout = 'dslice' if (world in (2, 4, 8) and d % world == 0 and d // world in (8, 16, 32)) else 'rows'
+    if layout not in ('dslice', 'rows'):
+        raise ValueError("dist_layout must be 'dslice', 'rows' or 'auto', got %r" % (layout,))
+    return (SlicedFREEDOM if layout == 'dslice' else RowShardedFREEDOM)(config, dataset)

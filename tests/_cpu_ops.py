@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 EMB_DIM = 64
+SLICE_WIDTHS = (8, 16, 32)        # hip_ops.SLICE_WIDTHS: one feature slice of a 64-wide table (mmrec_spmm_csr_f32 accepts them)
 BPR_LOGSIG, BPR_GAMMA = 0, 1
 
 
@@ -40,6 +41,7 @@ def _spmm_args(g, X, Z=None):
     _mat(X, "X")
     assert X.shape[0] >= g.n_cols, "X has %d rows, the graph %d columns" % (X.shape[0], g.n_cols)
     assert -(-X.shape[1] // EMB_DIM) <= 6, "row width %d > 384" % X.shape[1]
+    assert X.shape[1] % 4 == 0
     if Z is not None:
         _mat(Z, "Z")
         assert Z.shape[0] >= g.n_rows and Z.shape[1] == X.shape[1], "Z must be [>= n_rows, d]"
@@ -118,7 +120,7 @@ def spmm(g, X, Z=None):
 
 def lightgcn_mean(g, E0, n_layers):
     _spmm_args(g, E0)
-    _mat(E0, "E0", width_multiple=EMB_DIM)
+    _mat(E0, "E0", width_multiple=None if E0.shape[1] in SLICE_WIDTHS else EMB_DIM)
     assert g.n_rows == g.n_cols == E0.shape[0], "layer mean needs a square graph over the rows of E0"
     outs, cur = [E0], E0
     for _ in range(int(n_layers)):

@@ -1213,11 +1213,15 @@ def test_sharded_propagator_rccl_single_rank(ops, dev):
         dist.destroy_process_group()
 
 
-def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev):
-    """config `n_gpus`: the sharded FREEDOM plugin (row-sharded graphs + RCCL all-gather per layer forward and backward,
-    item-sharded feature tables with the projected batch rows exchanged, sharded evaluation) on the HIP kernels through
-    a single-rank RCCL group, collectives forced: one epoch of Trainer steps and an evaluation == the plain FREEDOM
-    plugin (world sizes 2 / 3 run on gloo with the CPU stand-ins: tests/test_dist_gloo.py)."""
+@pytest.mark.parametrize("layout", ["rows", "dslice"])
+def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
+    """config `n_gpus`: the sharded FREEDOM plugins on the HIP kernels through a single-rank RCCL group, collectives forced:
+    one epoch of Trainer steps and an evaluation == the plain FREEDOM plugin.  `dist_layout: rows` -- row-sharded graphs +
+    RCCL all-gather per layer forward and backward, item-sharded feature tables with the projected batch rows exchanged,
+    sharded evaluation; `dslice` -- the feature-sliced plugin (whole graphs, column-sliced id tables, all-reduced partial dot
+    products, full-width projection gradients summed back to the owners, tables all-gathered per evaluation).  World sizes
+    2 / 3 / 4 / 8 run on gloo with the CPU stand-ins (tests/test_dist_gloo.py); the slice kernels themselves are checked bit
+    for bit above (test_spmm_feature_slices_equal_the_d64_launch_bitwise)."""
     import os
     import socket
     import torch.distributed as dist
@@ -1229,9 +1233,11 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev):
         res = {}
         for sharded in (False, True):
             extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "dist_chunks": 2,
-                     "dist_force_collectives": True, "lazy_feature_adam": False}
+                     "dist_force_collectives": True, "lazy_feature_adam": False, "dist_layout": layout}
             config, train_data, valid_data = setup(tmp_path / ("s%d" % sharded), golden, "FREEDOM", extra, use_gpu=True)
             model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(config["device"])
+            assert type(model).__name__ == {(False, layout): "FREEDOM", (True, "rows"): "RowShardedFREEDOM",
+                                            (True, "dslice"): "SlicedFREEDOM"}[(sharded, layout)]
             gen = torch.Generator().manual_seed(3)
             keep = torch.multinomial(model.edge_values.detach().cpu(), int(model.edge_values.numel() * 0.2), generator=gen)
             model.set_kept_edges(keep.to(dev))

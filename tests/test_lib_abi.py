@@ -76,8 +76,10 @@ def test_workspace_sizes(lib):
 
 def test_argument_errors_without_gpu(lib):
     # argument validation happens on the host before any launch
+    assert lib.mmrec_spmm_csr_f32(None, None, None, None, None, None, None, None, 10, 24, 1.0, 0.0, 1.0,
+                                  256, None, None, 0, 0, None, None, None) == 10002   # d: not a multiple of 64, not a slice width
     assert lib.mmrec_spmm_csr_f32(None, None, None, None, None, None, None, None, 10, 32, 1.0, 0.0, 1.0,
-                                  256, None, None, 0, 0, None, None, None) == 10002   # d != 64
+                                  256, None, None, 0, 0, None, None, None) == 10001   # d = 32 is a feature slice: NULL pointers
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 65, None, None, None, 0, None) == 10001
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 5, None, None, None, 2, None) == 10001   # unknown flag
     assert lib.mmrec_linear_fwd_f32(None, None, None, None, 4, 6, 64, None, None) == 10002  # F % 4
