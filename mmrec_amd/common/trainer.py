@@ -70,6 +70,7 @@ class Trainer(AbstractTrainer):
         self.fused_eval = True if fused is None else bool(fused)
         dm = config['hip_device_metrics']
         self.device_metrics = True if dm is None else bool(dm)
+        self.eval_path, self.eval_paths = None, {}      # which path ranked the last evaluation / how often each one did
         # new key: bitwise-repeatable training (position-ordered gradient scatters).  Set from the config value EVERY time a
         # Trainer is built: the switch is process-wide (hip_ops.DETERMINISTIC), and a later Trainer of the same process --
         # a hyper-parameter sweep, quick_start's loop -- must not inherit the previous one's choice.
@@ -219,7 +220,8 @@ class Trainer(AbstractTrainer):
             v1 = time()
             _, test_result = self._valid_epoch(test_data)
             if verbose:
-                self.logger.info('epoch %d evaluating [time: %.2fs, valid_score: %f]' % (epoch_idx, v1 - v0, valid_score))
+                self.logger.info('epoch %d evaluating [time: %.2fs, valid_score: %f, ranked by: %s]' %
+                                 (epoch_idx, v1 - v0, valid_score, self.eval_path))
                 self.logger.info('valid result: \n' + dict2str(valid_result))
                 self.logger.info('test result: \n' + dict2str(test_result))
             if update_flag:
@@ -261,10 +263,21 @@ class Trainer(AbstractTrainer):
     def evaluate(self, eval_data, is_test=False, idx=0):
         self.model.eval()
         k = max(self.config['topk'])
-        fused = self.fused_eval and hasattr(self.model, 'full_sort_topk')
-        if fused:
+        # WHICH path ranks this evaluation is recorded (self.eval_path, the result log line) and, with the new key
+        # `strict_fused_eval`, enforced: a benchmark that silently timed rocBLAS + torch.topk would be a different measurement
+        strict = bool(self.config['strict_fused_eval'])
+        why_dense = None
+        if not self.fused_eval:
+            why_dense = 'hip_fused_eval: False'
+        elif not hasattr(self.model, 'full_sort_topk'):
+            why_dense = 'the model has no full_sort_topk'
+        else:
             from mmrec_amd import hip_ops
-            fused = k <= hip_ops.TOPK_MAX        # torch.topk takes any k; the kernels 128 (64 below 4096 items: the call says so)
+            if k > hip_ops.TOPK_MAX:             # torch.topk takes any k; the kernels 128 (64 below 4096 items: the call says so)
+                why_dense = 'max(topk) = %d > %d' % (k, hip_ops.TOPK_MAX)
+        if why_dense and strict and self.fused_eval:
+            raise RuntimeError('strict_fused_eval: the fused evaluation cannot serve this run (%s)' % why_dense)
+        fused = why_dense is None
         topk_batches = []
         for batch in eval_data:
             if fused:
@@ -273,11 +286,15 @@ class Trainer(AbstractTrainer):
                     continue
                 except Exception as ex:          # a shape the fused kernel does not serve: the reference's path
                     from mmrec_amd._lib import MMRecHipError
-                    if not isinstance(ex, MMRecHipError):
+                    if not isinstance(ex, MMRecHipError) or strict:
                         raise
+                    why_dense = 'the kernel refused the shape: %s' % ex
                     self.logger.warning('fused top-K evaluation unavailable for this model (%s); using the dense path' % ex)
                     fused = False
             topk_batches.append(self._dense_topk(batch, k))
+        self.eval_path = 'fused HIP score + mask + top-K' if why_dense is None else \
+            'dense (full_sort_predict + torch.topk, trainer.py:302-310): ' + why_dense
+        self.eval_paths[self.eval_path] = self.eval_paths.get(self.eval_path, 0) + 1
         if self.device_metrics and topk_batches and topk_batches[0].is_cuda:
             return self.evaluator.evaluate_device(topk_batches, eval_data, is_test=is_test, idx=idx)
         return self.evaluator.evaluate(topk_batches, eval_data, is_test=is_test, idx=idx)

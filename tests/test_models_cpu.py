@@ -188,6 +188,20 @@ def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     sizes.clear()
     res = t2.evaluate(valid_data)
     assert sizes and res["recall@5"] == whole["recall@5"] and "recall@70" in res
+    # round-3 review (weak 8): the path that ranked an evaluation is RECORDED, and `strict_fused_eval` refuses the fallback
+    assert trainer.eval_path.startswith("dense") and "hip_fused_eval: False" in trainer.eval_path
+    assert t2.eval_path.startswith("dense") and "refused the shape" in t2.eval_path and sum(t2.eval_paths.values()) == 1
+    config["topk"] = [5, 20]
+    t3 = Trainer(config, model)
+    t3.evaluate(valid_data)
+    assert t3.eval_path.startswith("fused")
+    from mmrec_amd._lib import MMRecHipError
+    config["topk"], config["strict_fused_eval"] = [5, 70], True
+    with pytest.raises(MMRecHipError):             # k = 70 on 90 items: the kernel says no, and strict mode lets it
+        Trainer(config, model).evaluate(valid_data)
+    config["topk"] = [5, 200]
+    with pytest.raises(RuntimeError, match="strict_fused_eval"):
+        Trainer(config, model).evaluate(valid_data)
 
 
 def test_adjacent_id_tables_layout(tmp_path, golden):
