@@ -211,11 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
                                                         const float* __restrict__ B,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ S, int M, int N, int K,
-                                                        int lds_, int ncols) {
+                                                        int lds_, int ncols, const int* __restrict__ m_live) {
     __shared__ __attribute__((aligned(1024))) float As0[128 * 32], As1[128 * 32], Bs0[128 * 32], Bs1[128 * 32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    if (m_live && m0 >= *m_live) return;   // a device-side row count (topk_wide.h: the re-scored queries): nothing to do here
     const int rows_a = min(128, M - m0), rows_b = max(0, min(128, N - n0));
     const i32x4 ra = raw_rsrc(A + (size_t)m0 * K, (unsigned)rows_a * (unsigned)K * 4u);
     const i32x4 rb = raw_rsrc(B + (size_t)n0 * K, (unsigned)rows_b * (unsigned)K * 4u);
@@ -290,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 
 // `ncols` columns of every row are written (>= N: the columns past N hold zeros + nothing else).
 inline void gemm_nt_launch(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
-                           int ldc, int ncols, hipStream_t s) {
+                           int ldc, int ncols, hipStream_t s, const int* m_live = nullptr) {
     hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + 127) / 128, (ncols + 127) / 128), dim3(256), 0, s, A, B, bias, C,
-                       M, N, K, ldc, ncols);
+                       M, N, K, ldc, ncols, m_live);
 }
 
 // Launch of gemm64_stream_kernel.  f tiles per workgroup: long walks win (measured: 8 tiles beat 2 even

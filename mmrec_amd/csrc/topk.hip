@@ -434,13 +434,14 @@ __global__ __launch_bounds__(256) void select_topk_kernel(
     float* S, int ld, int rows, int q0, int nc, int k,
     const float* __restrict__ gmax, int n_groups,
     const int32_t* __restrict__ mask_rowptr, const int32_t* __restrict__ mask_col,
-    int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+    const int* __restrict__ row_map, const int* __restrict__ rows_live) {   // (topk_wide.h: row ql is query row_map[ql], of *rows_live)
     __shared__ unsigned long long s_all[4][SEL_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = blockIdx.x * 4 + wave;
-    if (ql >= rows) return;   // no workgroup-level synchronisation below: waves are independent
+    if (ql >= rows || (rows_live && ql >= *rows_live)) return;   // no workgroup-level synchronisation below: waves are independent
     unsigned long long* list = s_all[wave];
-    const int q = q0 + ql;
+    const int q = row_map ? row_map[ql] : q0 + ql;
     float* row = S + (size_t)ql * ld;
     const float4* row4 = reinterpret_cast<const float4*>(row);
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m_hi = mask_rowptr ? mask_rowptr[q + 1] : 0;
@@ -545,6 +546,10 @@ __global__ __launch_bounds__(256) void select_topk_kernel(
     }
 }
 
+}  // namespace
+#include "topk_wide.h"
+namespace {
+
 struct TopkPlan {
     int n_tiles, n_split, tiles_per_wave, two_pass, tiles_per_group, n_groups, groups_per_wave;
     int materialise, qb_rows;   // kd == 64: score block of qb_rows queries in the workspace
@@ -613,7 +618,8 @@ extern "C" size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd,
                          al256((size_t)p.qb_rows * GEMM64_MAX_GROUPS * 4);
         // either path may serve the call (`flags` of mmrec_score_topk_f32 decides): size for both
         const size_t f = topk64_filter_applicable(nq, nc, kd, k) ? topk64_filter_workspace_bytes(nq, nc, kd, k) : 0;
-        return b > f ? b : f;
+        const size_t w = topk_wide_applicable(nq, nc, kd, k) ? topk_wide_extra_bytes(nc, kd, p.qb_rows) : 0;   // wide rows: + fp16 copies, lists
+        return (b > f ? b : f) + w;
     }
     size_t b = al256((size_t)kd_pad * ldc * 4);               // Ct
     if (kd != 64) b += al256((size_t)kd_pad * ldq * 4);        // Qt
@@ -659,16 +665,21 @@ static int score_topk_impl(const float* Q, const float* C, const void* prepared,
         }
         float* S = reinterpret_cast<float*>(ws); ws += al256((size_t)p.qb_rows * ldc * 4);
         float* gm = reinterpret_cast<float*>(ws);
+        if (!(flags & MMREC_TOPK_NO_FILTER) && topk_wide_applicable(nq, nc, kd, k))   // wide rows: fp16 pass + exact refinement
+            return topk_wide_launch(Q, C, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, S, ldc, p.qb_rows,
+                                    reinterpret_cast<char*>(gm) + al256((size_t)p.qb_rows * GEMM64_MAX_GROUPS * 4), s);
         for (int q0 = 0; q0 < nq; q0 += p.qb_rows) {
             const int rows = nq - q0 < p.qb_rows ? nq - q0 : p.qb_rows;
             if (kd == 64) {
                 const int groups = gemm64_stream_gmax_launch(Q + (size_t)q0 * 64, Ct, S, rows, ldc, gm, nc, s);
                 hipLaunchKernelGGL(select_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, S, ldc, rows,
-                                   q0, nc, k, gm, groups, mask_rowptr, mask_col, out_idx, out_val);
+                                   q0, nc, k, gm, groups, mask_rowptr, mask_col, out_idx, out_val, (const int*)nullptr,
+                                   (const int*)nullptr);
             } else {
                 gemm_nt_launch(Q + (size_t)q0 * kd, C, nullptr, S, rows, nc, kd, ldc, ldc, s);
                 hipLaunchKernelGGL(select_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, S, ldc, rows,
-                                   q0, nc, k, (const float*)nullptr, 0, mask_rowptr, mask_col, out_idx, out_val);
+                                   q0, nc, k, (const float*)nullptr, 0, mask_rowptr, mask_col, out_idx, out_val,
+                                   (const int*)nullptr, (const int*)nullptr);
             }
         }
         MMREC_RETURN_LAUNCH_STATUS();

@@ -80,7 +80,7 @@ def test_knn_graph_at_c5_item_count(modality):
     log("%s: identical neighbour sets on %.4f of the %d sampled rows (the rest: near-ties at the 10th score)" %
         (modality, same, rows.shape[0]))
     from tests._env import observed
-    floor = 0.99 if USE_GPU else 0.9
+    floor = 0.995 if USE_GPU else 0.9        # observed 1.0000 on 512 rows at both widths (profiles/r04_c5_pieces_knn.log)
     assert observed("c5_pieces.knn_%s_rows" % modality, same, floor) >= floor, same
 
 

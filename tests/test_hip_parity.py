@@ -691,6 +691,50 @@ def test_topk_general_kd_materialised(ops, dev, kd):
     _topk_check(ops, dev, Q, C, 50, None, exact_gap=1e-4)
 
 
+@pytest.mark.parametrize("kd,nq,nc,k", [(192, 700, 5003, 10), (384, 300, 20_011, 32), (4096, 260, 4500, 10), (4096, 129, 9000, 1)])
+def test_topk_wide_rows_fp16_pass_with_exact_refinement(ops, dev, kd, nq, nc, k):
+    """kd = 192 ... 4096, >= 4096 candidates, k <= 32 (csrc/topk_wide.h: the kNN builds over raw features, freedom.py:79-91):
+    fp16 matrix-core scores -> the 64 best approximate candidates per query -> margin test -> exact fp32 re-scoring, and a
+    rescue queue through the exact fp32 path for queries whose scores are too closely packed.  Row-normalised features with a
+    large common component (the relu image features), duplicated candidates (exact ties: lower id first), query rows scaled by
+    2^-30 and 2^+20, masks incl. a query's best candidates, one query whose candidates are ALL within 1e-4 of each other
+    (fails the margin test: rescue queue) and, in one case, 80 such queries (more than one rescue workgroup) -- vs
+    orc.mask_topk with the near-tie rule and vs the fp32 path (use_filter=False); two calls are bitwise identical."""
+    rng = np.random.default_rng(kd + nc + k)
+    base = np.maximum(rng.standard_normal((nc, kd)), 0).astype(np.float32) if kd == 4096 else \
+        rng.standard_normal((nc, kd)).astype(np.float32) + 0.5
+    C = base / np.linalg.norm(base, axis=1, keepdims=True)
+    Q = C[rng.choice(nc, nq, replace=False)].copy()            # kNN-like: the queries ARE candidates (self-similarity 1)
+    Q[3] *= np.float32(2.0) ** -30
+    Q[4] *= np.float32(2.0) ** 20
+    C[200:260] = C[77]                                          # 60 identical candidates ...
+    Q[5] = C[77]                                                # ... that are this query's best
+    n_flat = 80 if kd == 384 else 1
+    flat = rng.standard_normal(kd).astype(np.float32)
+    flat /= np.linalg.norm(flat)
+    C[1000:1400] = flat + (rng.standard_normal((400, kd)) * 1e-5).astype(np.float32)     # 400 candidates within ~1e-4 of each other
+    Q[10:10 + n_flat] = flat + (rng.standard_normal((n_flat, kd)) * 1e-5).astype(np.float32)
+    best = np.argsort(-(Q[:40].astype(np.float64) @ C.astype(np.float64).T), axis=1)[:, :3]
+    rows = np.concatenate([rng.integers(0, nq, 5 * nq), np.repeat(np.arange(40), 3)])
+    cols = np.concatenate([rng.integers(0, nc, 5 * nq), best.reshape(-1)])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    from tests.test_topk_fuzz_gpu import check_lists
+    rp, col = ops.mask_to_csr(mask, nq, dev)
+    Qd, Cd = D(Q, dev), D(C, dev)
+    idx, val = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)
+    check_lists("wide rows kd %d" % kd, idx.cpu(), val.cpu(), torch.from_numpy(Q), torch.from_numpy(C), mask, k)
+    if k > 1:
+        masked5 = set(mask[1][mask[0] == 5].tolist())
+        ties = [c for c in [77] + list(range(200, 260)) if c not in masked5]
+        assert idx[5].cpu().tolist()[:min(k, len(ties))] == sorted(ties)[:min(k, len(ties))]      # exact ties: lowest ids first
+    again = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)
+    assert torch.equal(again[0], idx) and torch.equal(again[1], val)
+    m_idx, m_val = ops.score_topk(Qd, Cd, k, rp, col, return_values=True, use_filter=False)
+    np.testing.assert_allclose(val.cpu().numpy(), m_val.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    assert (m_idx == idx).float().mean() > 0.97           # (the flat queries' 400 near-identical candidates order differently)
+
+
 def test_topk_adversarial_ascending_scores(ops, dev):
     """scores increase with the candidate id: every candidate beats the threshold (max compactions)."""
     nq, nc = 33, 7000     # two-pass path: every group maximum is its last candidate

@@ -23,7 +23,9 @@ def test_generator_covers_every_plan_switch_and_is_deterministic():
     for edge in (4096, 32768, 65536, 131072):
         assert ((ncs < edge) & (ncs >= edge - 70)).any() and ((ncs >= edge) & (ncs < edge + 70)).any(), edge
     assert (ncs < 200).any() and (ncs > 200_000).any()
-    assert {c["kd"] for c in metas} == {64, 128} and max(c["k"] for c in metas) == 128 and min(c["k"] for c in metas) == 1
+    assert {c["kd"] for c in metas} == {64, 128, 192, 384} and max(c["k"] for c in metas) == 128 and min(c["k"] for c in metas) == 1
+    wide = [c for c in metas if c["kd"] > 128 and c["nc"] >= 4096]
+    assert any(c["k"] <= 32 for c in wide) and any(c["k"] > 32 for c in wide) and all(c["k"] <= 64 for c in wide)
     tags = {t for c in cases for t in c["tags"]}
     assert {"qspread", "cspread", "outliers", "ties", "heavy", "bestmasked", "zeroq", "starved", "dupq"} <= tags, tags
     a, b = F.gen_case(7, scale=0.02, work=3.0e5), F.gen_case(7, scale=0.02, work=3.0e5)

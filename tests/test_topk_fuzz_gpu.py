@@ -6,7 +6,9 @@ neither of its two real bugs (subnormal query rows, overflowing lists) except by
 cases over
 
     nq in [1, 3000], nc in [1, 300,000] (with extra weight on both sides of every plan switch: 4096 / 32,768 / 65,536 /
-    131,072 candidates), k in [1, 128] (<= 64 below 4096 candidates: the materialised path's limit), kd in {64, 128},
+    131,072 candidates), k in [1, 128] (<= 64 below 4096 candidates and for the wide rows: the materialised path's limit), kd in
+    {64, 128} and, in a quarter of the cases, {192, 384} (the fp16 pass + exact refinement of csrc/topk_wide.h for k <= 32,
+    the fp32 path above),
     mask density (none / sparse / the train-positive shape / heavy users with 600 and 5,000 masked items, optionally the
     query's BEST candidates masked), per-row norm spread up to 2^+-40 on the queries and 2^+-12 on the candidates, a common
     component (what LightGCN smoothing produces), outlying candidate rows (x 5..25: trained item tables), all-zero query
@@ -25,8 +27,8 @@ import torch
 
 from oracle import mmrec_oracle as orc
 
-N_CASES = 240
-WORK = 3.0e7         # nq * nc per case: the CPU oracle forms the [nq, nc] block (fp32 and float64)
+N_CASES = 200
+WORK = 1.5e7         # nq * nc per case: the CPU oracle forms the [nq, nc] block (fp32 and float64)
 SCALE = 1.0          # the CPU twin shrinks the candidate counts
 
 _NC_EDGES = (4096, 32768, 65536, 131072)
@@ -36,7 +38,7 @@ def gen_case(seed, scale=None, work=None, meta_only=False):
     scale = SCALE if scale is None else scale
     work = WORK if work is None else work
     rng = np.random.default_rng(1_000_003 * seed + 17)
-    kd = int(rng.choice([64, 128]))
+    kd = int(rng.choice([64, 128, 64, 128, 64, 128, 192, 384]))      # wide rows (csrc/topk_wide.h) in a quarter of the cases
     kind = int(rng.integers(0, 10))
     if kind == 0:
         nc = int(rng.integers(1, 200))
@@ -57,7 +59,7 @@ def gen_case(seed, scale=None, work=None, meta_only=False):
     if rng.random() < 0.15:
         nq = int(rng.choice([1, 31, 32, 33, 255, 256, 257, 511, 513]))
     nq = max(1, min(nq, int(work // nc)))
-    kmax = min(nc, 128 if nc >= 4096 else 64)
+    kmax = min(nc, 128 if (nc >= 4096 and kd <= 128) else 64)
     k = int(rng.choice([1, 5, 10, 20, 50, 64, 65, 100, 128])) if rng.random() < 0.6 else int(rng.integers(1, 129))
     k = max(1, min(k, kmax))
     if meta_only:
