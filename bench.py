@@ -1166,6 +1166,17 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                         pr["counters_source"] = "profiles/r03_mfma_pmc.json (a committed profile of these kernels, NOT measured in this run)"
                     except Exception:
                         pr["mfma_util_counters"] = None
+            try:      # graphs WITH locality (round-3 review item 5): what a build-time relabelling buys
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import spmm_locality_probe
+                gi = spmm_locality_probe.measure(dev, log=log)
+                gi["what"] = ("a config-5-sized graph with PLANTED communities (2,000 users x 1,000 items, 90 % of the interactions "
+                              "inside), one SpMM layer: ids grouped by community / randomly permuted (what a dataset's arbitrary ids "
+                              "look like) / randomly permuted and relabelled at build time by hip_ops.PermutedGraph (same bits as "
+                              "the plain graph); the benchmark's own graph has no structure to find")
+                line["extra"]["c5_grouped_ids"] = gi
+            except Exception as ex:
+                line["extra"]["c5_grouped_ids"] = {"error": repr(ex)}
             try:
                 ne = nnz_total // 2
                 line["extra"]["c5_train_step_roofline"] = c5_train_step_roofline(dev, sh.n_users, sh.n_items, r[:ne],

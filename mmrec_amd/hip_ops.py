@@ -222,6 +222,87 @@ class CsrGraph:
                         long_row_threshold=self.long_row_threshold, rowptr_host=rph)
 
 
+def _mode_labels(rows, lab_c, n_rows, n_labels):
+    """for every row the most frequent label among its neighbours (ties: the smallest label); -1 for rows without any"""
+    key = rows.astype(np.int64) * n_labels + lab_c
+    key.sort()
+    start = np.flatnonzero(np.concatenate([[True], key[1:] != key[:-1]]))
+    cnt = np.diff(np.concatenate([start, [key.shape[0]]]))
+    k = key[start]
+    r, lab = k // n_labels, k % n_labels
+    o = np.lexsort((lab, -cnt, r))               # per row: highest count first, then the smallest label
+    r_s = r[o]
+    first = np.concatenate([[True], r_s[1:] != r_s[:-1]])
+    out = np.full(n_rows, -1, dtype=np.int64)
+    out[r_s[first]] = lab[o][first]
+    return out
+
+
+def locality_order(rowptr_host, colidx_host, n, how, n_left=None, iters=4):
+    """A relabelling of the n nodes of a SQUARE graph for gather locality (round-3 review item 5): new id = perm[old id].
+      'degree'     ids by descending degree (hot rows share cache lines and pages);
+      'rcm'        reverse Cuthill-McKee on the structure (scipy.sparse.csgraph): good for mesh-like graphs, not for
+                   interaction graphs (a few random edges make every BFS level the whole graph);
+      'community'  `iters` rounds of label propagation (a node takes its neighbours' most frequent label), nodes then
+                   ordered by label: the members of a community get adjacent ids, so the rows a workgroup gathers are the
+                   rows its neighbours in the grid gather.  Bipartite graphs (`n_left`: ids below it are one side) update one
+                   side from the other in turn.  A graph without communities just gets some permutation.
+    Host side, integer, deterministic."""
+    rp = np.asarray(rowptr_host, dtype=np.int64)
+    deg = np.diff(rp)
+    ci = np.asarray(colidx_host, dtype=np.int64)
+    if how == "degree":
+        order = np.argsort(-deg, kind="stable")               # order[new] = old
+    elif how == "rcm":
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        a = sp.csr_matrix((np.ones(ci.shape[0], dtype=np.int8), ci.astype(np.int32), rp.astype(np.int32)), shape=(n, n))
+        order = np.asarray(reverse_cuthill_mckee(a, symmetric_mode=True), dtype=np.int64)
+    elif how == "community":
+        rows = np.repeat(np.arange(n, dtype=np.int64), deg)
+        lab = np.arange(n, dtype=np.int64)
+        sides = [slice(None)] if not n_left else [rows < n_left, rows >= n_left]
+        for _ in range(int(iters)):
+            for side in sides:                                 # (bipartite: left from right, then right from the new left)
+                new = _mode_labels(rows[side], lab[ci[side]], n, n)
+                lab = np.where(new >= 0, new, lab)
+        order = np.lexsort((np.arange(n), lab))
+    else:
+        raise ValueError("reorder must be 'degree', 'rcm' or 'community', got %r" % (how,))
+    perm = np.empty(n, dtype=np.int64)
+    perm[order] = np.arange(n, dtype=np.int64)
+    return perm
+
+
+class PermutedGraph:
+    """A square CsrGraph with its node ids RELABELLED at build time (`reorder`: 'degree' | 'rcm' | 'community'; locality_order) and the
+    permutation kept next to it.  Rows keep their nonzeros in their original order (stable relabelling), so every row's sum
+    is the unpermuted graph's bit for bit: `lightgcn_mean(pg, E0, L)` / `spmm(pg, X)` permute the input once, run all
+    layers in the relabelled space and permute the result back -- equal to the plain graph's results BITWISE."""
+
+    def __init__(self, g: CsrGraph, reorder, n_left=None):
+        if g.n_rows != g.n_cols:
+            raise _lib.MMRecHipError("PermutedGraph needs a square graph")
+        dev, n = g.rowptr.device, g.n_rows
+        idx, val = g.to_coo_host()
+        perm = locality_order(g.rowptr_host, idx[1], n, reorder, n_left=n_left)
+        self.base, self.reorder = g, reorder
+        self.perm = torch.from_numpy(perm).to(dev)                     # new id of old node
+        inv = np.empty(n, dtype=np.int64)
+        inv[perm] = np.arange(n, dtype=np.int64)
+        self.inv = torch.from_numpy(inv).to(dev)                       # old node of new id
+        self.graph = CsrGraph.from_coo_host(np.stack([perm[idx[0]], perm[idx[1]]]), val, n, n, dev, symmetric=g.symmetric,
+                                            long_row_threshold=g.long_row_threshold)     # stable: in-row order kept
+        self.n_rows = self.n_cols = n
+        self.nnz = g.nnz
+
+    def to_new(self, X):
+        return X.index_select(0, self.inv)
+
+    def to_old(self, Xp):
+        return Xp.index_select(0, self.perm)
+
+
 def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.0, beta=1.0,
              acc_scale=1.0):
     """Y = alpha*A@X (+ beta*Z);  acc_out = acc_scale*(acc_in + Y).  No autograd."""
@@ -270,6 +351,9 @@ def spmm(g: CsrGraph, X, Z=None):
     """A @ X (+ Z), differentiable in X and Z.  replaces torch.sparse.mm (freedom.py:167,172) and PyG's
     mean-aggregating propagate (mmgcn.py:205-213).  Row widths that are not a multiple of 64 are
     zero-padded for the kernel (aggregation is column-wise independent) and sliced back."""
+    if isinstance(g, PermutedGraph):
+        out = spmm(g.graph, g.to_new(X), None if Z is None else g.to_new(Z))
+        return g.to_old(out)
     d = X.shape[1]
     if d % EMB_DIM and d not in SLICE_WIDTHS:
         pad = EMB_DIM - d % EMB_DIM
@@ -318,7 +402,9 @@ class _LightGCNMean(torch.autograd.Function):
         return t, None, None
 
 
-def lightgcn_mean(g: CsrGraph, E0, n_layers):
+def lightgcn_mean(g, E0, n_layers):
+    if isinstance(g, PermutedGraph):      # relabelled graph: one permutation in, all layers in the new id space, one out
+        return g.to_old(_LightGCNMean.apply(g.to_new(E0), g.graph, n_layers))
     return _LightGCNMean.apply(E0, g, n_layers)
 
 

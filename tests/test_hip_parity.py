@@ -188,6 +188,43 @@ def test_lightgcn_mean_on_feature_slices_forward_and_backward_bitwise(ops, dev):
         assert torch.equal(o.detach(), out.detach()[:, cols]) and torch.equal(Es.grad, E0.grad[:, cols]), s
 
 
+@pytest.mark.parametrize("how", ["degree", "rcm", "community"])
+def test_relabelled_graph_equals_the_plain_graph_bitwise(ops, dev, how):
+    """hip_ops.PermutedGraph (round-3 review item 5): node ids relabelled at build time for gather locality ('degree': hot rows
+    adjacent; 'rcm': reverse Cuthill-McKee, neighbours get nearby ids), the permutation kept on the graph, inputs / outputs
+    permuted once per propagation.  A row keeps its nonzeros in their original order, so forward AND backward of
+    lightgcn_mean and spmm equal the plain graph's BIT FOR BIT -- on the Baby-shaped graph (long rows, multi-chunk rows)."""
+    from mmrec_amd import synth
+    nu, ni, eu, ei = synth.shaped_edges("baby", seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    n = nu + ni
+    g = ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
+    pg = ops.PermutedGraph(g, how, n_left=nu)
+    assert sorted(pg.perm.cpu().tolist()) == list(range(n)) and torch.equal(pg.inv[pg.perm], torch.arange(n, device=dev))
+    # structure: new row perm[r] holds old row r's entries, relabelled, in the same order
+    idx_o, val_o = g.to_coo_host()
+    idx_n, val_n = pg.graph.to_coo_host()
+    perm = pg.perm.cpu().numpy()
+    rp_o, rp_n = g.rowptr_host.astype(np.int64), pg.graph.rowptr_host.astype(np.int64)
+    for row in (0, 17, nu + 3, int(np.argmax(np.diff(rp_o)))):
+        a, b = slice(rp_o[row], rp_o[row + 1]), slice(rp_n[perm[row]], rp_n[perm[row] + 1])
+        assert np.array_equal(perm[idx_o[1][a]], idx_n[1][b]) and np.array_equal(val_o[a], val_n[b])
+    gen = torch.Generator().manual_seed(2)
+    E0 = (torch.randn(n, 64, generator=gen) * 0.1).to(dev)
+    G = torch.randn(n, 64, generator=gen).to(dev)
+    outs = []
+    for graph in (g, pg):
+        E = E0.clone().requires_grad_()
+        o = ops.lightgcn_mean(graph, E, 3)
+        o.backward(G)
+        Z = E0.clone().requires_grad_()
+        o2 = ops.spmm(graph, Z, Z=Z)
+        o2.backward(G)
+        outs.append((o.detach(), E.grad, o2.detach(), Z.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_spmm_last_arriver_row_finish_equals_two_launches(ops, dev, d):
     """Graphs of <= 2^18 rows finish a multi-chunk row INSIDE the launch (mmrec_spmm_csr_f32 `long_tickets`, ABI 7: the chunk

@@ -332,3 +332,43 @@ def test_ground_truth_csr_from_flat_lists_equals_per_list_sort():
     assert np.array_equal(ids.numpy(), ref) and np.array_equal(rp.numpy(), np.concatenate([[0], np.cumsum(lens)]))
     rp, ids = hip_ops.flat_to_csr(np.zeros(0, np.int64), np.zeros(3, np.int64), "cpu")
     assert rp.tolist() == [0, 0, 0, 0] and ids.numel() == 1
+
+
+def test_locality_order_is_a_permutation_and_groups_neighbours():
+    """hip_ops.locality_order (the relabelling behind hip_ops.PermutedGraph): 'degree' puts the highest-degree nodes first;
+    'rcm' shrinks the bandwidth of a graph whose communities were hidden by a random id permutation (neighbours get nearby
+    ids).  Host side, integer, deterministic."""
+    import scipy.sparse as sp
+    from mmrec_amd import hip_ops
+    rng = np.random.default_rng(0)
+    n, comm = 3000, 100                                            # 30 communities of 100 nodes, ids scrambled
+    a = rng.integers(0, n, 30000)
+    b = (a // comm) * comm + rng.integers(0, comm, 30000)          # edges inside a community
+    scramble = rng.permutation(n)
+    rows, cols = np.concatenate([scramble[a], scramble[b]]), np.concatenate([scramble[b], scramble[a]])
+    m = sp.csr_matrix((np.ones(rows.shape[0]), (rows, cols)), shape=(n, n))
+    m.sum_duplicates()
+    rp, ci = m.indptr.astype(np.int64), m.indices
+    for how in ("degree", "rcm", "community"):
+        perm = hip_ops.locality_order(rp, ci, n, how)
+        assert sorted(perm.tolist()) == list(range(n))
+        assert np.array_equal(perm, hip_ops.locality_order(rp, ci, n, how))
+    deg = np.diff(rp)
+    pd = hip_ops.locality_order(rp, ci, n, "degree")
+    assert deg[np.argsort(pd)][0] == deg.max() and np.all(np.diff(deg[np.argsort(pd)]) <= 0)
+    pr = hip_ops.locality_order(rp, ci, n, "rcm")
+    r_of = np.repeat(np.arange(n), deg)
+    spread_before = np.abs(r_of - ci).mean()
+    spread_after = np.abs(pr[r_of] - pr[ci]).mean()
+    assert spread_after < 0.2 * spread_before, (spread_before, spread_after)
+    # label propagation finds the hidden communities, also with 10 % of the edges going anywhere (where RCM's BFS levels blow up)
+    far = rng.integers(0, n, 3000), rng.integers(0, n, 3000)
+    m2 = sp.csr_matrix((np.ones(rows.shape[0] + 6000), (np.concatenate([rows, far[0], far[1]]), np.concatenate([cols, far[1], far[0]]))),
+                       shape=(n, n))
+    m2.sum_duplicates()
+    rp2, ci2 = m2.indptr.astype(np.int64), m2.indices
+    pc = hip_ops.locality_order(rp2, ci2, n, "community")
+    r2 = np.repeat(np.arange(n), np.diff(rp2))
+    assert np.abs(pc[r2] - pc[ci2]).mean() < 0.25 * np.abs(r2 - ci2).mean()
+    with pytest.raises(ValueError):
+        hip_ops.locality_order(rp, ci, n, "nope")

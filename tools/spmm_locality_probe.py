@@ -37,34 +37,63 @@ def community_edges(nu, ni, ne, cu, ci, inside=0.9, seed=0):
     return key // ni, key % ni, n_comm
 
 
-def main():
-    dev = torch.device("cuda:0")
+def time_layer(g, x, y, reps=20):
+    for _ in range(3):
+        hip_ops.spmm_raw(g, x, Y=y)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        hip_ops.spmm_raw(g, x, Y=y)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def measure(dev, log=print):
+    """-> dict: ms per layer with ids grouped by community / randomly permuted / randomly permuted then RELABELLED at build time
+    (hip_ops.PermutedGraph: 'community' = label propagation, 'degree', 'rcm'), the relabelling's host time and the two
+    permutation passes a propagation pays for it (d = 64; d = 8: one feature slice)."""
     nu, ni, ne = 1_000_000, 500_000, 10_000_000
     eu, ei, _ = community_edges(nu, ni, ne, 2000, 1000)
     rng = np.random.default_rng(1)
     pu, pi = rng.permutation(nu), rng.permutation(ni)
     gen = torch.Generator(device=dev).manual_seed(0)
-    for name, (a, b) in (("grouped by community", (eu, ei)), ("randomly permuted ids", (pu[eu], pi[ei]))):
+    n = nu + ni
+    out = {}
+
+    def graph(a, b):
         o = np.lexsort((b, a))
         r, c, v = synth.sym_norm_coo(a[o], b[o], nu, ni)
-        g = hip_ops.CsrGraph.from_coo_device(torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev),
-                                             torch.from_numpy(v).to(dev), nu + ni, nu + ni, symmetric=True)
-        x = torch.rand(nu + ni, 64, device=dev, generator=gen) - 0.5
-        y = torch.empty_like(x)
-        for _ in range(3):
-            hip_ops.spmm_raw(g, x, Y=y)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            hip_ops.spmm_raw(g, x, Y=y)
-            x, y = y, x
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 20 * 1e3
-        alg = 264.0 * g.nnz + 260.0 * (nu + ni)
-        print("%-24s nnz %d: %.3f ms per layer = %.1f G edges/s, gather model %.2f TB/s (%.2f of 8 TB/s), compulsory %.2f TB/s" %
-              (name, g.nnz, ms, g.nnz / ms / 1e6, alg / ms / 1e9, alg / ms / 1e9 / 8.0, (8.0 * g.nnz + 516.0 * (nu + ni)) / ms / 1e9),
-              flush=True)
-        del g, x, y
+        return hip_ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
+    x = {d: torch.rand(n, d, device=dev, generator=gen) - 0.5 for d in (64, 8)}
+    y = {d: torch.empty_like(x[d]) for d in x}
+    for name, (a, b) in (("grouped", (eu, ei)), ("scrambled", (pu[eu], pi[ei]))):
+        g = graph(a, b)
+        out[name] = {"ms_per_layer_d%d" % d: time_layer(g, x[d], y[d]) for d in x}
+        log("%-28s d64 %.3f ms  d8 %.3f ms per layer" % (name, out[name]["ms_per_layer_d64"], out[name]["ms_per_layer_d8"]))
+        if name == "scrambled":
+            for how in ("community", "degree", "rcm"):
+                t0 = time.time()
+                pg = hip_ops.PermutedGraph(g, how, n_left=nu)
+                host_s = time.time() - t0
+                rec = {"ms_per_layer_d%d" % d: time_layer(pg.graph, x[d], y[d]) for d in x}
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    pg.to_old(pg.to_new(x[64]))
+                torch.cuda.synchronize()
+                rec["ms_two_permutation_passes_d64"] = (time.perf_counter() - t0) / 10 * 1e3
+                rec["relabel_host_s"] = host_s
+                out["scrambled+" + how] = rec
+                log("%-28s d64 %.3f ms  d8 %.3f ms per layer; permute in + out %.3f ms per propagation; relabelling %.1f s on the host"
+                    % ("scrambled + " + how, rec["ms_per_layer_d64"], rec["ms_per_layer_d8"], rec["ms_two_permutation_passes_d64"], host_s))
+                del pg
+        del g
+    return out
+
+
+def main():
+    measure(torch.device("cuda:0"))
 
 
 if __name__ == "__main__":
