@@ -130,20 +130,26 @@ def test_spmm_row_shards_bitwise_equal(ops, dev):
         assert torch.equal(Yb, Y[r0:r1])
 
 
-@pytest.mark.parametrize("n_rows,thr", [(777, 8), (777, 256), (300_000, None)])
-def test_spmm_feature_slices_equal_the_d64_launch_bitwise(ops, dev, n_rows, thr):
+@pytest.mark.parametrize("n_rows,thr,sorted_cols", [(777, 8, False), (777, 256, False), (300_000, None, False),
+                                                    (300_000, None, True), (1_100_000, None, True)])
+def test_spmm_feature_slices_equal_the_d64_launch_bitwise(ops, dev, n_rows, thr, sorted_cols):
     """The feature-sliced multi-GPU layout (csrc/spmm_narrow.hip): a rank owns 64 / P columns of every table
     and the whole graph, `Y[:, s] = A X[:, s]` needs no exchange.  World 1 here: the P = 2 / 4 / 8 slices ([n, 32 / 16 / 8]
     contiguous) through mmrec_spmm_csr_f32 one after the other == the columns of the d = 64 launch BIT FOR BIT -- short
     rows, empty rows, single-chunk and multi-chunk long rows (both sides of the chunk size), both row-finish forms of the
-    d = 64 kernel (last-arriver up to 2^18 rows, two launches above), plain and full epilogue (alpha, beta Z, running sum)."""
+    d = 64 kernel (last-arriver up to 2^18 rows, two launches above), plain and full epilogue (alpha, beta Z, running sum),
+    and both slice kernels: the row-per-sub-group launch and, on column-sorted graphs, the in-step column-window launch
+    (spmm_narrow_phased_kernel; 1.1M rows: two resident generations at d = 8, five at d = 32)."""
     rng = np.random.default_rng(n_rows)
     n_cols = n_rows if n_rows > 1000 else 500
     degs = rng.integers(0, 40, n_rows)
     degs[[5, 6, 100, 101, 102, 103, n_rows - 1]] = [0, 1, 5000, 512, 513, 20_000, 300]
     idx, val = _random_csr(rng, n_rows, n_cols, degs)
+    if sorted_cols:      # column-sorted rows (get_norm_adj_mat's graphs): the slice launches walk the column space in step --
+        o = np.lexsort((idx[1], idx[0]))     # > 2^18 rows, X slice > 8 MB; 1.1M rows: more than one resident generation (d = 8)
+        idx, val = idx[:, o], val[o]
     g = ops.CsrGraph.from_coo_host(idx, val, n_rows, n_cols, dev, long_row_threshold=thr)
-    assert g.n_long > 0 and g.n_chunks > g.n_long
+    assert g.n_long > 0 and g.n_chunks > g.n_long and g.cols_sorted == sorted_cols
     X = D(rng.standard_normal((n_cols, 64)).astype(np.float32), dev)
     Z = D(rng.standard_normal((n_rows, 64)).astype(np.float32), dev)
     A0 = D(rng.standard_normal((n_rows, 64)).astype(np.float32), dev)

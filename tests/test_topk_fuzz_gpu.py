@@ -173,6 +173,17 @@ def check_case(ops, dev, case):
 
 
 def check_lists(what, idx, val, Qt, Ct, mask, k, s64=None):
+    # the GPU box has 256 host cores: torch's CPU ops on these mid-sized blocks spend their time waking threads (83 min of user
+    # time for an 8-minute suite), so the checker runs on a bounded pool
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    try:
+        return _check_lists(what, idx, val, Qt, Ct, mask, k, s64)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _check_lists(what, idx, val, Qt, Ct, mask, k, s64=None):
     """Device lists `idx` [nq, k] (+ optional values `val`) of the queries Qt against the candidates Ct under `mask` ([2, n],
     rows relative to Qt) vs the oracle's trainer step, with the rules of this file's header.  CPU tensors.  `s64`: the
     float64 score block when the caller has formed it already (wide rows, in chunks)."""
