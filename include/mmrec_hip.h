@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 8
+#define MMREC_ABI_VERSION 7
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -84,21 +84,6 @@ int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float
                        int32_t long_row_threshold, const int32_t* long_rows,
                        const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
                        float* partials, int32_t* long_tickets, mmrec_stream_t stream);
-
-/* ABI 8 -- mmrec_spmm_csr_f32 on a FEATURE SLICE (d = 8 / 16 / 32: 64 / P columns of a 64-wide table, the feature-sliced
- * multi-GPU layout) with two facts the kernel cannot see in its arguments: n_cols (the extent of X the launch gathers from)
- * and, in `flags`, MMREC_SPMM_COLS_SORTED: every row's nonzeros are in ascending column order (get_norm_adj_mat builds its
- * graph that way, freedom.py:102-126).  With it, graphs whose X slice exceeds the L2 are propagated with all resident rows
- * walking the column space in step, so that their gathers hit L2 (a slice launch is otherwise bound by one 128-B fabric
- * line per nonzero).  The flag is a locality hint only: rows are summed in CSR order either way, results are bit-identical
- * to mmrec_spmm_csr_f32 on the same slice and to the columns of its d = 64 launch.  Other arguments as there (no tickets:
- * multi-chunk rows are always finished by the second launch). */
-#define MMREC_SPMM_COLS_SORTED 1
-int mmrec_spmm_csr_slice_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, float* Y,
-                             const float* Z, const float* acc_in, float* acc_out, int32_t n_rows, int32_t n_cols, int32_t d,
-                             float alpha, float beta, float acc_scale, int32_t long_row_threshold,
-                             const int32_t* long_rows, const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
-                             float* partials, int32_t flags, mmrec_stream_t stream);
 
 /* One LayerGCN layer in one launch (layergcn.py:131-135): y = A x ; w[row] = cosine_similarity(y[row], ego[row]) with
  * eps 1e-8 per norm ; scaled = w * y (the next layer's input) ; acc_out = acc_in + scaled (acc_in NULL: acc_out = scaled;

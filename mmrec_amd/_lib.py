@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MMREC_HIP_LIB: load another build of the same library (kernel A/B measurements: tools/prof_topk_filter.py)
 LIB_PATH = os.environ.get("MMREC_HIP_LIB") or os.path.join(_PKG, "lib", "libmmrec_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 7
 
 _P = c_void_p  # every device/host pointer travels as void*
 
@@ -26,8 +26,6 @@ SIGNATURES = {
     "mmrec_error_string": (c_char_p, [c_int32]),
     "mmrec_spmm_csr_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_float,
                                      c_float, c_float, c_int32, _P, _P, c_int32, c_int32, _P, _P, _P]),
-    "mmrec_spmm_csr_slice_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float,
-                                           c_float, c_float, c_int32, _P, _P, c_int32, c_int32, _P, c_int32, _P]),
     "mmrec_spmm_csr_f32_layergcn": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
                                               _P, _P, c_int32, c_int32, _P, _P, _P]),
     "mmrec_spmm_plan_count": (c_int32, [_P, c_int32, c_int32, _P, _P]),

@@ -461,9 +461,9 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
         return MMREC_ERR_BAD_ARG;
     if (Y == X) return MMREC_ERR_BAD_ARG;  // other rows still gather from X
     if (narrow)
-        return spmm_narrow_launch(rowptr, colidx, vals, X, Y, Z, acc_in, acc_out, n_rows, 0, d, alpha, beta, acc_scale,
+        return spmm_narrow_launch(rowptr, colidx, vals, X, Y, Z, acc_in, acc_out, n_rows, d, alpha, beta, acc_scale,
                                   n_long > 0 ? long_row_threshold : INT32_MAX, long_rows, long_chunk_ptr, n_long,
-                                  n_long > 0 ? n_chunks : 0, partials, false, mmrec_stream(stream));
+                                  n_long > 0 ? n_chunks : 0, partials, mmrec_stream(stream));
     RowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale, nullptr, nullptr, nullptr};
     hipStream_t s = mmrec_stream(stream);
     // small (cache-resident, latency-bound) graphs: one row per 16-lane group; large graphs: four
@@ -486,26 +486,6 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     }
 #undef MMREC_SPMM_CASE
     MMREC_RETURN_LAUNCH_STATUS();
-}
-
-// mmrec_spmm_csr_f32 on a feature slice (d = 8 / 16 / 32) with what the kernel cannot see from its arguments: the column count
-// (the extent of X the launch gathers from) and whether every row's nonzeros are in ascending column order -- then all resident
-// rows walk the column space in step and their gathers hit L2 (spmm_narrow.hip).  Same results bit for bit.
-extern "C" int mmrec_spmm_csr_slice_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
-                                        float* Y, const float* Z, const float* acc_in, float* acc_out, int32_t n_rows,
-                                        int32_t n_cols, int32_t d, float alpha, float beta, float acc_scale,
-                                        int32_t long_row_threshold, const int32_t* long_rows,
-                                        const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks, float* partials,
-                                        int32_t flags, mmrec_stream_t stream) {
-    if (d != 8 && d != 16 && d != 32) return MMREC_ERR_UNSUPPORTED;
-    if (flags & ~MMREC_SPMM_COLS_SORTED) return MMREC_ERR_BAD_ARG;
-    if (n_rows < 0 || n_cols < 0 || n_long < 0 || n_chunks < 0 || long_row_threshold < 0) return MMREC_ERR_BAD_ARG;
-    if (n_rows == 0) return 0;
-    if (!rowptr || !X || (!Y && !acc_out) || (acc_out && !acc_in) || Y == X) return MMREC_ERR_BAD_ARG;
-    if (n_long > 0 && (!long_rows || !long_chunk_ptr || !partials || n_chunks <= 0)) return MMREC_ERR_BAD_ARG;
-    return spmm_narrow_launch(rowptr, colidx, vals, X, Y, Z, acc_in, acc_out, n_rows, n_cols, d, alpha, beta, acc_scale,
-                              n_long > 0 ? long_row_threshold : INT32_MAX, long_rows, long_chunk_ptr, n_long,
-                              n_long > 0 ? n_chunks : 0, partials, (flags & MMREC_SPMM_COLS_SORTED) != 0, mmrec_stream(stream));
 }
 
 // One LayerGCN layer in ONE launch: y = A x, w = cos(y, ego) per row, scaled = w y, acc_out = acc_in + scaled

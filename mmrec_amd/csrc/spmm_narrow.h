@@ -3,8 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// cols_sorted: every row's nonzeros are in ascending column order (a hint for locality only: sums are in CSR order either way)
 int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, float* Y,
-                       const float* Z, const float* acc_in, float* acc_out, int n_rows, int n_cols, int d, float alpha,
-                       float beta, float acc_scale, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr,
-                       int n_long, int n_chunks, float* partials, bool cols_sorted, hipStream_t s);
+                       const float* Z, const float* acc_in, float* acc_out, int n_rows, int d, float alpha, float beta,
+                       float acc_scale, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr, int n_long,
+                       int n_chunks, float* partials, hipStream_t s);

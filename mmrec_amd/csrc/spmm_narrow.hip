@@ -163,135 +163,17 @@ __global__ __launch_bounds__(256) void spmm_narrow_long_reduce_kernel(
     }
 }
 
-// ---- column-sorted rows: all resident rows walk the column space IN STEP ----------------------------------------------
-// A slice launch is bound by 128-B fabric lines, about one per nonzero (L2 hit rate 29 % at config 5: the 48 MB slice of X
-// is 12 x an XCD's L2).  When every row's nonzeros are sorted by column (the normalised user-item graph: freedom.py:102-126
-// builds it row-major sorted), the CSR order of a row IS ascending column order, so a wave may interleave the work of its rows
-// freely as long as each row's own terms stay in order.  This kernel makes ALL rows of a launch resident at once -- a wave owns
-// R x (64 / LPR) rows, their accumulators and cursors in registers -- and walks the columns in PHASES of `blk_rows` rows of X
-// (2 MB: half an XCD's L2): in phase p every row consumes its nonzeros with column < (p + 1) blk_rows.  Waves do the same amount
-// of work per phase on average, so without any barrier the whole chip gathers from the same 2-MB window at any time and the
-// gathers hit L2.  A row's sum is the same fma chain as ever: same bits.  Long rows stay with the chunk blocks.
-__device__ __forceinline__ float w_sel(unsigned m, float a, float b) {       // m all ones: a, all zeros: b
-    return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
-}
-
-template <int LPR, int R>
-__global__ __launch_bounds__(256, 4) void spmm_narrow_phased_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-    const float* __restrict__ X, NarrowEpilogue ep, int row_lo, int row_hi, int long_t, int n_cols, int blk_rows) {
-    constexpr int SPW = 64 / LPR;            // rows a wave handles per register set
-    const int lane = threadIdx.x & 63, t = lane % LPR, p = lane / LPR;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int base = row_lo + wv * (R * SPW) + p;
-    const float4* X4 = reinterpret_cast<const float4*>(X);
-    float4 acc[R];
-    int cur[R], rem[R], c[R];
-    float v[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int row = base + i * SPW;
-        acc[i] = f4_zero();
-        cur[i] = 0;
-        rem[i] = -1;                         // no such row / a long row: nothing to do, nothing to store
-        c[i] = INT32_MAX;
-        v[i] = 0.f;
-        if (row < row_hi) {
-            const int s = rowptr[row], n = rowptr[row + 1] - s;
-            if (n <= long_t) {
-                cur[i] = s;
-                rem[i] = n;
-                if (n > 0) {
-                    c[i] = __builtin_nontemporal_load(colidx + s);
-                    v[i] = __builtin_nontemporal_load(vals + s);
-                }
-            }
-        }
-    }
-    for (int lo = 0; lo < n_cols; lo += blk_rows) {
-        const int hi = lo + blk_rows >= n_cols ? INT32_MAX : lo + blk_rows;
-        for (;;) {
-            bool mine = false;
-#pragma unroll
-            for (int i = 0; i < R; ++i) mine |= c[i] < hi;       // (c == INT32_MAX: row finished / absent)
-            if (__ballot(mine) == 0ull) break;                   // the wave has nothing left in this window
-#pragma unroll
-            for (int i0 = 0; i0 < R; i0 += 4) {                  // four rows' gathers in flight per lane
-                // No branches, and no selects the compiler could turn back into branches (it sinks a load whose value is only
-                // used under a condition into that condition's block and drains it there, s_waitcnt vmcnt(0) per load): the
-                // "taken" decision is a bit mask, every update and / or arithmetic on it.  The sched_barriers keep the three
-                // stages apart: left alone the scheduler serialises load -> wait -> use row by row (lowest register pressure).
-                float4 x[4];
-                unsigned m[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    m[u] = (unsigned)-(int)(c[i] < hi);                        // all ones: this row consumes its nonzero now
-                    const int col = (c[i] & (int)m[u]) | (lo & (int)~m[u]);    // idle slots re-read the window's first row (an L2 hit)
-                    x[u] = X4[(size_t)col * LPR + t];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                int nc[4];
-                float nv[4];
-                unsigned more[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    cur[i] += (int)(m[u] & 1u);
-                    rem[i] -= (int)(m[u] & 1u);
-                    more[u] = (unsigned)-(int)(rem[i] > 0);
-                    const int at = cur[i] & (int)more[u];                      // (always a valid address; re-reads are L1 hits)
-                    nc[u] = __builtin_nontemporal_load(colidx + at);
-                    nv[u] = __builtin_nontemporal_load(vals + at);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    const float4 f = f4_fma(v[i], x[u], acc[i]);
-                    acc[i].x = w_sel(m[u], f.x, acc[i].x);
-                    acc[i].y = w_sel(m[u], f.y, acc[i].y);
-                    acc[i].z = w_sel(m[u], f.z, acc[i].z);
-                    acc[i].w = w_sel(m[u], f.w, acc[i].w);
-                    const int next_c = (nc[u] & (int)more[u]) | (INT32_MAX & (int)~more[u]);
-                    c[i] = (next_c & (int)m[u]) | (c[i] & (int)~m[u]);
-                    v[i] = w_sel(m[u], nv[u], v[i]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-        if (rem[i] >= 0) store_row<LPR>(ep, base + i * SPW, t, acc[i]);
-}
-
 template <int LPR>
 void launch(hipStream_t s, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
-            const NarrowEpilogue& ep, int n_rows, int n_cols, int long_t, const int32_t* long_rows,
-            const int32_t* long_chunk_ptr, int n_long, int n_chunks, float* partials, bool phased) {
+            const NarrowEpilogue& ep, int n_rows, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr,
+            int n_long, int n_chunks, float* partials) {
     constexpr int CPB = 16 / LPR, SPB = 256 / LPR;
+    const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
+    const int blocks = (n_rows + SPB * rows_per_group - 1) / (SPB * rows_per_group);
     const int chunk_blocks = (n_chunks + CPB - 1) / CPB;
-    if (phased) {
-        // long rows first (their chunk blocks alone: no row blocks), then the short rows in launches of as many rows as the chip
-        // holds resident at once (4 waves per SIMD x R rows per sub-group), every launch walking the column windows in step
-        constexpr int R = 8, ROWS_PER_WG = 4 * R * (64 / LPR), WG_RESIDENT = 1024;
-        if (chunk_blocks > 0)
-            hipLaunchKernelGGL(spmm_narrow_rows_kernel<LPR>, dim3(chunk_blocks), dim3(256), 0, s, rowptr, colidx, vals, X, ep, 0,
-                               long_t, 1, long_rows, long_chunk_ptr, n_long, n_chunks, chunk_blocks, partials);
-        const int blk_rows = (2 << 20) / (16 * LPR);                 // 2 MB of X rows per window
-        const long cap = (long)WG_RESIDENT * ROWS_PER_WG;
-        for (long lo = 0; lo < n_rows; lo += cap) {
-            const int hi = (int)(lo + cap < n_rows ? lo + cap : n_rows);
-            hipLaunchKernelGGL((spmm_narrow_phased_kernel<LPR, R>), dim3((hi - (int)lo + ROWS_PER_WG - 1) / ROWS_PER_WG), dim3(256),
-                               0, s, rowptr, colidx, vals, X, ep, (int)lo, hi, long_t, n_cols, blk_rows);
-        }
-    } else {
-        const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
-        const int blocks = (n_rows + SPB * rows_per_group - 1) / (SPB * rows_per_group);
-        hipLaunchKernelGGL(spmm_narrow_rows_kernel<LPR>, dim3(blocks + chunk_blocks), dim3(256), 0, s, rowptr, colidx, vals, X,
-                           ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, n_chunks, chunk_blocks,
-                           partials);
-    }
+    hipLaunchKernelGGL(spmm_narrow_rows_kernel<LPR>, dim3(blocks + chunk_blocks), dim3(256), 0, s, rowptr, colidx, vals, X,
+                       ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, n_chunks, chunk_blocks,
+                       partials);
     if (n_long > 0 && n_chunks > n_long)     // at least one row spans several chunks
         hipLaunchKernelGGL(spmm_narrow_long_reduce_kernel<LPR>, dim3((n_long + CPB - 1) / CPB), dim3(256), 0, s, long_rows,
                            long_chunk_ptr, n_long, partials, ep);
@@ -300,23 +182,22 @@ void launch(hipStream_t s, const int32_t* rowptr, const int32_t* colidx, const f
 }  // namespace
 
 int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, float* Y,
-                       const float* Z, const float* acc_in, float* acc_out, int n_rows, int n_cols, int d, float alpha,
-                       float beta, float acc_scale, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr,
-                       int n_long, int n_chunks, float* partials, bool cols_sorted, hipStream_t s) {
+                       const float* Z, const float* acc_in, float* acc_out, int n_rows, int d, float alpha, float beta,
+                       float acc_scale, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr, int n_long,
+                       int n_chunks, float* partials, hipStream_t s) {
     const NarrowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale};
-    // in-step column windows: for graphs whose rows are column-sorted (the caller says so: locality is all that depends on it,
-    // the sums are in CSR order either way) and whose X slice does not fit an XCD's L2 anyway
-    const bool phased = cols_sorted && n_cols > 0 && (size_t)n_cols * d * 4 > ((size_t)8 << 20) && n_rows > (1 << 18);
-#define MMREC_NARROW_CASE(D, L)                                                                                          \
-    case D:                                                                                                              \
-        launch<L>(s, rowptr, colidx, vals, X, ep, n_rows, n_cols, long_t, long_rows, long_chunk_ptr, n_long, n_chunks,   \
-                  partials, phased);                                                                                     \
-        break;
     switch (d) {
-        MMREC_NARROW_CASE(8, 2) MMREC_NARROW_CASE(16, 4) MMREC_NARROW_CASE(32, 8)
+        case 8:
+            launch<2>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials);
+            break;
+        case 16:
+            launch<4>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials);
+            break;
+        case 32:
+            launch<8>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials);
+            break;
         default:
             return MMREC_ERR_UNSUPPORTED;
     }
-#undef MMREC_NARROW_CASE
     return (int)hipGetLastError();
 }

@@ -17,8 +17,6 @@ import torch
 from . import _lib
 
 EMB_DIM = 64
-SPMM_COLS_SORTED = 1          # MMREC_SPMM_COLS_SORTED
-SLICE_PHASED = True           # (A/B switch of tools/dslice_probe.py: False keeps the plain slice kernel on column-sorted graphs)
 SLICE_WIDTHS = (8, 16, 32)    # one feature slice of a 64-wide table: 64 / P columns per rank of the feature-sliced layout (csrc/spmm_narrow.hip)
 SPMM_CHUNK = 512
 LONG_ROW_DEFAULT = None    # by graph size, see default_long_row_threshold
@@ -118,7 +116,6 @@ class CsrGraph:
         self.long_row_threshold = int(default_long_row_threshold(self.n_cols) if long_row_threshold is None
                                       else long_row_threshold)
         self._t = self if symmetric else None
-        self._cols_sorted = None
         self._plan(rowptr_host)
 
     # -- plan: rows longer than the threshold are cut into fixed-size chunks (host side, C helper)
@@ -161,22 +158,6 @@ class CsrGraph:
                 except RuntimeError:
                     pass                         # (a faulted device: nothing more will run on it anyway)
             raise
-
-    @property
-    def cols_sorted(self):
-        """every row's nonzeros in ascending column order (get_norm_adj_mat's graphs are: freedom.py:102-126; the per-epoch
-        pruned graph keeps the multinomial draw's order and is not).  One device reduction, cached; a locality hint for the
-        feature-slice launches -- never a correctness matter."""
-        if self._cols_sorted is None:
-            if self.nnz < 2:
-                self._cols_sorted = True
-            else:
-                ok = self.colidx[1:] >= self.colidx[:-1]
-                starts = self.rowptr[1:-1].long()                     # first entry of rows 1 .. n-1: a new row may start lower
-                starts = starts[(starts > 0) & (starts < self.nnz)]
-                ok[starts - 1] = True
-                self._cols_sorted = bool(ok.all())
-        return self._cols_sorted
 
     def partials_for(self, d):
         """long-row workspace (n_chunks x d fp32), allocated once per embedding width"""
@@ -336,14 +317,6 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
             _chk(t, torch.float32, nm, 2)
             if t.shape[0] < g.n_rows or t.shape[1] != d:
                 raise _lib.MMRecHipError("%s must be [>=%d, %d]" % (nm, g.n_rows, d))
-    if d in SLICE_WIDTHS:      # a feature slice: the entry point that also takes the column count and the sortedness hint
-        g.checked(lib.mmrec_spmm_csr_slice_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Y), _p(Z), _p(acc_in),
-                                               _p(acc_out), g.n_rows, g.n_cols, d, float(alpha), float(beta), float(acc_scale),
-                                               g.long_row_threshold, _p(g.long_rows), _p(g.long_chunk_ptr), g.n_long,
-                                               g.n_chunks, _p(g.partials_for(d)),
-                                               SPMM_COLS_SORTED if (SLICE_PHASED and g.cols_sorted) else 0, _stream()),
-                  "spmm_csr_slice_f32")
-        return Y if Y is not None else acc_out
     g.checked(lib.mmrec_spmm_csr_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Y), _p(Z),
                                      _p(acc_in), _p(acc_out), g.n_rows, d, float(alpha),
                                      float(beta), float(acc_scale), g.long_row_threshold,

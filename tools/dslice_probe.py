@@ -60,18 +60,11 @@ def main():
     out = {}
     for name, (g, n_x) in graphs.items():
         t = {d: time_layer(g, n_x, d, args.reps) for d in (64, 32, 16, 8)}
-        plain = None
-        if g.cols_sorted:                      # A/B: the in-step column-window launch (default on sorted graphs) vs the plain one
-            hip_ops.SLICE_PHASED = False
-            plain = {d: time_layer(g, n_x, d, args.reps) for d in (32, 16, 8)}
-            hip_ops.SLICE_PHASED = True
         alg = {d: ((8 + 4 * d) * g.nnz + (4 + 4 * d) * g.n_rows) / 1e9 for d in t}
         out[name] = {"nnz": g.nnz, "rows": g.n_rows, "ms_per_layer": {str(d): round(x, 4) for d, x in t.items()},
                      "implied_speedup": {str(64 // d): round(t[64] / t[d], 2) for d in (32, 16, 8)},
                      "algorithmic_GB": {str(d): round(x, 3) for d, x in alg.items()},
-                     "algorithmic_TBps": {str(d): round(alg[d] / t[d], 2) for d in t},
-                     "cols_sorted": bool(g.cols_sorted),
-                     "ms_per_layer_plain_slice_kernel": None if plain is None else {str(d): round(x, 4) for d, x in plain.items()}}
+                     "algorithmic_TBps": {str(d): round(alg[d] / t[d], 2) for d in t}}
         print(name, json.dumps(out[name]), flush=True)
     if args.out:
         with open(args.out, "w") as f:
