@@ -544,7 +544,10 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         self.dropout = config['dropout']
         n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
         self.lazy_feature_adam = lazy_adam_enabled(config, n_feat)
-        self.graph_capturable = False
+        # new key `dist_graph_step`: replay the sliced step -- its small collectives included -- as a hipGraph (RCCL collectives
+        # are capturable; common/graph_step.py falls back to eager launches if a capture fails).  Off by default: it could only
+        # be exercised on a one-rank group so far.
+        self.graph_capturable = bool(config['dist_graph_step'])
         nu, ni = self.n_users, self.n_items
         self.n_nodes = nu + ni
 
