@@ -70,3 +70,45 @@ def test_sharded_propagation_over_rccl_world_2(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert open(os.path.join(str(tmp_path), "ok")).read() == "1"
+
+
+def _worker_sliced(rank, world, port, out_dir):
+    """the feature-sliced layout on real devices: every rank propagates its 64 / world columns with no collective, the slices
+    are all-gathered (the layout's one bulk exchange) and must equal the unsliced launch bit for bit, forward and backward"""
+    import torch.distributed as dist
+    from mmrec_amd import hip_ops, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    nu, ni, eu, ei = synth.shaped_edges("baby", seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    n = nu + ni
+    g = hip_ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
+    gen = torch.Generator(device=dev).manual_seed(3)              # same seed: the same tables on every rank
+    E = ((torch.rand(n, 64, device=dev, generator=gen) - 0.5) * 0.2).requires_grad_()
+    G = torch.rand(n, 64, device=dev, generator=gen) - 0.5
+    ref = hip_ops.lightgcn_mean(g, E, 3)
+    ref.backward(G)
+    w = 64 // world
+    cols = slice(rank * w, (rank + 1) * w)
+    Es = E.detach()[:, cols].contiguous().requires_grad_()
+    o = hip_ops.lightgcn_mean(g, Es, 3)
+    o.backward(G[:, cols].contiguous())
+    parts = torch.empty(world * 2 * n, w, device=dev)
+    dist.all_gather_into_tensor(parts, torch.cat((o.detach(), Es.grad)))
+    both = parts.view(world, 2, n, w).permute(1, 2, 0, 3).reshape(2, n, 64)
+    ok = torch.equal(both[0], ref.detach()) and torch.equal(both[1], E.grad)
+    flag = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_sliced"), "w").write(str(int(flag.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_feature_sliced_propagation_over_rccl_world_2(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_sliced, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), "ok_sliced")).read() == "1"
