@@ -443,10 +443,18 @@ def extra_baby(dev):
         # the projection's roofline (north_star: "rocprof MFMA utilisation reported"): FLOP-derived fraction of the fp32-input
         # MFMA peak measured here, the X bytes it streams, and the COUNTER view (SQ_VALU_MFMA_BUSY_CYCLES over the busy CU
         # cycles, tools/pmc_kernels.py linear -> profiles/r03_mfma_pmc.json, collected in its own rocprofv3 passes)
-        proj = {"bound": "mfma (fp32 inputs) at the HBM ridge", "peak_tflops": MFMA_F32_PEAK_TF,
+        proj = {"bound": "the HBM stream of X since round 4: the forward runs on the 16-bit matrix cores with split operands "
+                         "(x = hi + 2^-11 lo' in fp16, three fp16 MFMA products per 16 k, fp32 accumulators, fp32-accurate); the "
+                         "fp32-MFMA form it replaces was bound by the 157.3 TFLOP/s fp32 matrix pipe",
+                "peak_tflops": MFMA_F32_PEAK_TF, "kernel": "linear_fwd_dma_f16x3_kernel" if hip_ops.LINEAR_F16X3 else "linear_fwd_dma_kernel",
                 "baby": {"n": ni, "F": 4096, "fwd_us": dt * 1e6, "fwd_tflops": out["baby_linear4096_fwd_tflops"],
                          "fwd_frac": out["baby_linear4096_fwd_frac_mfma_f32"], "x_bytes_streamed": 4.0 * ni * 4096,
-                         "x_gbs": 4.0 * ni * 4096 / dt / 1e9}}
+                         "x_gbs": 4.0 * ni * 4096 / dt / 1e9, "frac_hbm_stream": 4.0 * ni * 4096 / dt / 1e9 / HBM_PEAK_GBS}}
+        hip_ops.LINEAR_F16X3 = False                       # the fp32-MFMA kernel, for the A/B
+        dt32 = timeit(lambda: hip_ops.linear(X, W, b), reps=100, warm=20, windows=5)
+        hip_ops.LINEAR_F16X3 = True
+        proj["baby"]["fwd_us_fp32_mfma_kernel"] = dt32 * 1e6
+        proj["baby"]["fwd_frac_fp32_mfma_kernel"] = 2.0 * ni * 4096 * 64 / dt32 / 1e12 / MFMA_F32_PEAK_TF
         out["projection_roofline"] = proj
         out["_projection_items"] = ni            # (the counters are collected at the end: a child process under rocprofv3)
     # forward + backward (dW, db, dX) of the projection, as FREEDOM / BM3 run it every batch

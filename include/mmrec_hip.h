@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 7
+#define MMREC_ABI_VERSION 8
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -177,6 +177,13 @@ int mmrec_infonce_bwd_f32(const int64_t* ids, int32_t batch, int32_t d, float ta
 size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out);
 int mmrec_linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int32_t n,
                          int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
+/* ABI 8 -- the same projection on the 16-bit matrix cores with SPLIT operands: x = hi + 2^-11 lo' in fp16, three fp16 MFMA
+ * products per 16 k instead of eight fp32 ones (fp32-input MFMA is 1/16 of the 16-bit rate and bounds the fp32 form), fp32
+ * accumulators, error <= 2^-21 |x||w| per term -- as accurate against float64 as the fp32 form.  Domain |x|, |w| < 32768.
+ * Arguments, workspace (mmrec_linear_workspace_bytes) and results (to rounding) as mmrec_linear_fwd_f32; F % 32 != 0 is served
+ * by it. */
+int mmrec_linear_fwd_split_f32(const float* X, const float* W, const float* b, float* Y, int32_t n, int32_t F,
+                               int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW, float* db, int32_t n,
                            int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_x_f32(const float* dY, const float* W, float* dX, int32_t n, int32_t F,

@@ -77,6 +77,8 @@ class Trainer(AbstractTrainer):
         from mmrec_amd import hip_ops
         hip_ops.set_deterministic(hip_ops.DETERMINISTIC_DEFAULT if config['hip_deterministic'] is None
                                   else bool(config['hip_deterministic']))
+        if config['hip_linear_split'] is not None:      # new key: False keeps the projection's forward on the fp32 matrix pipe
+            hip_ops.LINEAR_F16X3 = bool(config['hip_linear_split'])
 
     def _build_optimizer(self):
         kinds = {'adam': optim.Adam, 'sgd': optim.SGD, 'adagrad': optim.Adagrad, 'rmsprop': optim.RMSprop}

@@ -205,6 +205,127 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------- forward on the 16-bit matrix cores, fp32-accurate (split operands)
+// fp32-input MFMA runs at 1/16 of the 16-bit rate, and at K = 4096 it -- not the 115 MB ... 8.2 GB stream of X -- bounds the
+// projection (0.55 of ITS peak at Amazon-Baby).  Every fp32 number is hi + lo with hi = fp16(x) and lo = x - hi, |lo| <= 2^-11 |x|;
+// with lo' = fp16(2^11 lo) both parts are normal fp16 numbers and
+//     x w = hi_x hi_w + 2^-11 (hi_x lo'_w + lo'_x hi_w) + lo_x lo_w,        |lo_x lo_w| <= 2^-22 |x w|,
+// three v_mfma_f32_32x32x16_f16 products (exact in the fp32 accumulators) instead of eight fp32 MFMAs per 16 k, two accumulator
+// sets (hi hi / cross terms) combined once at the end.  Error per product <= 2^-21 |x w| (the dropped lo lo term + the rounding
+// of lo' to 11 bits) -- the size of fp32's own accumulation error over K = 4096 terms; measured against float64 it is as
+// accurate as the fp32 kernel (tests).  Domain: |x|, |w| < 32768 (fp16 range; a feature table or a weight of that size is a bug
+// upstream; `hip_ops.LINEAR_F16X3 = False` / config `hip_linear_split: False` keep the fp32 kernel).
+// X streams through the same LDS-DMA ring as linear_fwd_dma_kernel (fp32 tiles, split in registers: ~6 VALU per element, about
+// the time of the 12 MFMAs they feed); W is split ONCE per call into the workspace in the tile layout the DMA wants (per 32-k
+// block and row: 32 hi halves | 32 lo' halves = the same 128 B as the fp32 tile row).  Bound: the HBM stream of X.
+typedef __attribute__((ext_vector_type(8))) _Float16 g_half8;
+
+__global__ __launch_bounds__(256) void linear_w_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wsp) {
+    // one thread per (row, 32-k block): 32 floats in, 32 hi halves + 32 lo' halves out
+    const int blocks = F / 32, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 64 * blocks) return;
+    const int row = t / blocks, kb = t % blocks;
+    const float* src = W + (size_t)row * F + kb * 32;
+    _Float16* dst = reinterpret_cast<_Float16*>(Wsp + (size_t)row * F + kb * 32);
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+        const float w = src[k];
+        const _Float16 hi = (_Float16)w;
+        dst[k] = hi;
+        dst[32 + k] = (_Float16)((w - (float)hi) * 2048.f);
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const float* __restrict__ X,
+                                                                      const float* __restrict__ Wsp,
+                                                                      const float* __restrict__ bias,
+                                                                      float* __restrict__ out, int n, int F,
+                                                                      int k_chunk) {
+    __shared__ __attribute__((aligned(1024))) float Xs0[LIN_BM * DM_BK], Xs1[LIN_BM * DM_BK], Xs2[LIN_BM * DM_BK];
+    __shared__ __attribute__((aligned(1024))) float Ws0[64 * DM_BK], Ws1[64 * DM_BK], Ws2[64 * DM_BK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * LIN_BM;
+    const int kb = blockIdx.y * k_chunk, ke = min(kb + k_chunk, F);
+    const int T = (ke - kb) / DM_BK;
+    const int rows_left = min(LIN_BM, n - m0);
+    const i32x4 rx = raw_rsrc(X + (size_t)m0 * F, (unsigned)rows_left * (unsigned)F * 4u);
+    const i32x4 rw = raw_rsrc(Wsp, 64u * (unsigned)F * 4u);
+    int vx[4], vw[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 32 * wave + 8 * j + (lane >> 3);
+        vx[j] = r * F * 4 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * wave + 8 * j + (lane >> 3);
+        vw[j] = r * F * 4 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    auto issue = [&](float* xs, float* ws, int t) {
+        const int so = (kb + t * DM_BK) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16<NT>(rx, lds_addr(xs + (4 * wave + j) * 256), vx[j], so);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) lds_dma16<false>(rw, lds_addr(ws + (2 * wave + j) * 256), vw[j], so);
+    };
+    const int i = lane & 31, h = lane >> 5, g = (i >> 1) & 7;
+    f32x16 hh0 = {0}, hh1 = {0}, cx0 = {0}, cx1 = {0};      // hi x hi and cross-term accumulators of the two 32-output tiles
+    auto compute = [&](const float* xs, const float* ws) {
+        const float* xa = xs + (32 * wave + i) * DM_BK;
+        const float* wb = ws + i * DM_BK;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {                     // MFMA step st: k = 16 st + 8 h ... + 7 of the 32-k tile
+            const int c0 = 4 * st + 2 * h;
+            const float4 xa0 = *reinterpret_cast<const float4*>(xa + ((c0 ^ g) << 2));
+            const float4 xa1 = *reinterpret_cast<const float4*>(xa + (((c0 + 1) ^ g) << 2));
+            const float xv[8] = {xa0.x, xa0.y, xa0.z, xa0.w, xa1.x, xa1.y, xa1.z, xa1.w};
+            g_half8 ah, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 hi = (_Float16)xv[e];
+                ah[e] = hi;
+                al[e] = (_Float16)((xv[e] - (float)hi) * 2048.f);
+            }
+            const int ch = ((2 * st + h) ^ g) << 2, cl = ((4 + 2 * st + h) ^ g) << 2;     // hi / lo' chunks of the W tile row
+            const g_half8 bh0 = *reinterpret_cast<const g_half8*>(wb + ch), bl0 = *reinterpret_cast<const g_half8*>(wb + cl);
+            const g_half8 bh1 = *reinterpret_cast<const g_half8*>(wb + 32 * DM_BK + ch);
+            const g_half8 bl1 = *reinterpret_cast<const g_half8*>(wb + 32 * DM_BK + cl);
+            hh0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, hh0, 0, 0, 0);
+            hh1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, hh1, 0, 0, 0);
+            cx0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, cx0, 0, 0, 0);
+            cx1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, cx1, 0, 0, 0);
+            cx0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, cx0, 0, 0, 0);
+            cx1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, cx1, 0, 0, 0);
+        }
+    };
+    auto step = [&](const float* xc, const float* wc, float* xn, float* wn, int t) {
+        if (t + 1 < T) MMREC_WAIT_VM(6); else MMREC_WAIT_VM(0);  // my pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();                            // everyone's have; tile t-1 is consumed
+        if (t + 2 < T) issue(xn, wn, t + 2);
+        compute(xc, wc);
+    };
+    if (T > 0) issue(Xs0, Ws0, 0);
+    if (T > 1) issue(Xs1, Ws1, 1);
+    for (int t = 0; t < T;) {
+        step(Xs0, Ws0, Xs2, Ws2, t); if (++t >= T) break;
+        step(Xs1, Ws1, Xs0, Ws0, t); if (++t >= T) break;
+        step(Xs2, Ws2, Xs1, Ws1, t); ++t;
+    }
+    float* dst = out + (size_t)blockIdx.y * n * 64;
+    const float b0 = (bias && gridDim.y == 1) ? bias[i] : 0.f;
+    const float b1 = (bias && gridDim.y == 1) ? bias[32 + i] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 32 + d_row(r, lane);
+        if (row < n) {
+            dst[(size_t)row * 64 + i] = fmaf(cx0[r], 1.f / 2048.f, hh0[r]) + b0;
+            dst[(size_t)row * 64 + 32 + i] = fmaf(cx1[r], 1.f / 2048.f, hh1[r]) + b1;
+        }
+    }
+}
+
 // out[idx] = sum_s part[s][idx] (+ bias[idx % 64]) in slab order; total = n*64 (multiple of 4).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int nslab,
                                                           size_t slab_elems,
@@ -474,7 +595,8 @@ extern "C" size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out
     int s1, c1, s2, c2;
     pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &s1, &c1);
     pick_split(ceil_div(F, BW_BF), n, BW_BK, &s2, &c2);
-    const size_t fwd = s1 > 1 ? (size_t)s1 * n * 64 * sizeof(float) : 0;
+    // forward: partial slabs, then (mmrec_linear_fwd_split_f32) the 64 x F split copy of W
+    const size_t fwd = ((s1 > 1 ? (size_t)s1 * n * 64 * sizeof(float) : 0) + 255) / 256 * 256 + (size_t)64 * F * sizeof(float);
     const size_t bww = ((s2 > 1 ? (size_t)s2 * 64 * F : 0) + (size_t)s2 * 64) * sizeof(float);
     return fwd > bww ? fwd : bww;
 }
@@ -510,6 +632,37 @@ extern "C" int mmrec_linear_fwd_f32(const float* X, const float* W, const float*
         const size_t elems = (size_t)n * 64;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0,
                            s, part, nsplit, elems, b, Y);
+    }
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+// mmrec_linear_fwd_f32 on the 16-bit matrix cores with split operands (fp32-accurate: see linear_fwd_dma_f16x3_kernel).  F % 32 != 0
+// takes the fp32 kernels.  Workspace: mmrec_linear_workspace_bytes (the split copy of W lives behind the partial slabs).
+extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const float* b, float* Y, int32_t n, int32_t F,
+                                          int32_t out, void* workspace, mmrec_stream_t stream) {
+    if (out != 64 || F <= 0 || (F & 3)) return MMREC_ERR_UNSUPPORTED;
+    if ((F % DM_BK) != 0) return mmrec_linear_fwd_f32(X, W, b, Y, n, F, out, workspace, stream);
+    if (n < 0) return MMREC_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!X || !W || !Y || !workspace) return MMREC_ERR_BAD_ARG;
+    int nsplit, chunk;
+    pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &nsplit, &chunk);
+    hipStream_t s = mmrec_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    float* Wsp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
+                                          ((nsplit > 1 ? (size_t)nsplit * n * 64 * sizeof(float) : 0) + 255) / 256 * 256);
+    hipLaunchKernelGGL(linear_w_split_kernel, dim3(ceil_div(64 * (F / 32), 256)), dim3(256), 0, s, W, F, Wsp);
+    float* dst = nsplit == 1 ? Y : part;
+    const dim3 grid(ceil_div(n, LIN_BM), nsplit);
+    const bool nt = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);
+    if (nt)
+        hipLaunchKernelGGL(linear_fwd_dma_f16x3_kernel<true>, grid, dim3(256), 0, s, X, Wsp, b, dst, n, F, chunk);
+    else
+        hipLaunchKernelGGL(linear_fwd_dma_f16x3_kernel<false>, grid, dim3(256), 0, s, X, Wsp, b, dst, n, F, chunk);
+    if (nsplit > 1) {
+        const size_t elems = (size_t)n * 64;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, part, nsplit, elems,
+                           b, Y);
     }
     MMREC_RETURN_LAUNCH_STATUS();
 }

@@ -17,6 +17,10 @@ import torch
 from . import _lib
 
 EMB_DIM = 64
+# The 4096 -> 64 projection's forward on the 16-bit matrix cores with split operands (x = hi + 2^-11 lo' in fp16, three fp16 MFMA
+# products per 16 k; as accurate against float64 as the fp32-MFMA kernel, which is bound by the 1/16-rate fp32 matrix pipe and
+# not by the stream of X).  Domain |x|, |w| < 32768.  False (config `hip_linear_split: False`): the fp32 kernel.
+LINEAR_F16X3 = True
 SLICE_WIDTHS = (8, 16, 32)    # one feature slice of a 64-wide table: 64 / P columns per rank of the feature-sliced layout (csrc/spmm_narrow.hip)
 SPMM_CHUNK = 512
 LONG_ROW_DEFAULT = None    # by graph size, see default_long_row_threshold
@@ -829,8 +833,8 @@ class _Linear(torch.autograd.Function):
             b = _chk(b.contiguous(), torch.float32, "b", 1)
         Y = torch.empty(n, 64, dtype=torch.float32, device=X.device)
         ws = _ws(lib.mmrec_linear_workspace_bytes(n, F, 64), X.device)
-        _lib.check(lib.mmrec_linear_fwd_f32(_p(X), _p(W), _p(b), _p(Y), n, F, 64, _p(ws), _stream()),
-                   "linear_fwd")
+        fwd = lib.mmrec_linear_fwd_split_f32 if LINEAR_F16X3 else lib.mmrec_linear_fwd_f32
+        _lib.check(fwd(_p(X), _p(W), _p(b), _p(Y), n, F, 64, _p(ws), _stream()), "linear_fwd")
         ctx.save_for_backward(X, W)
         ctx.has_b = b is not None
         return Y

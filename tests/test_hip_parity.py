@@ -619,6 +619,37 @@ def test_linear_fwd_bwd(ops, dev, n, F, bias):
         close(bd.grad, b.grad, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,F", [(3000, 4096), (7050, 384), (513, 4480), (40_000, 4096)])
+def test_linear_split_forward_is_as_accurate_as_the_fp32_kernel(ops, dev, n, F):
+    """mmrec_linear_fwd_split_f32 (ABI 8; hip_ops.LINEAR_F16X3, the default): the projection's forward as three fp16 MFMA products
+    of split operands x = hi + 2^-11 lo'.  Against float64 its error is within 2 x the fp32-MFMA kernel's (both ~1e-7 of the
+    result's scale), on relu-like features, rows scaled by 1e4 and 1e-6, a zero row, weights of mixed magnitude -- and the
+    two kernels agree to 1e-6 of the row scale."""
+    g = torch.Generator().manual_seed(n + F)
+    X = torch.relu(torch.randn(n, F, generator=g))
+    X[1] *= 1e4
+    X[2] *= 1e-6
+    X[3] = 0.0
+    W = torch.randn(64, F, generator=g) / F ** 0.5
+    W[:8] *= 50.0
+    W[8:16] *= 1e-3
+    b = torch.randn(64, generator=g)
+    ref = X.double() @ W.double().t() + b.double()
+    Xd, Wd, bd = X.to(dev), W.to(dev), b.to(dev)
+    out = {}
+    try:
+        for split in (True, False):
+            ops.LINEAR_F16X3 = split
+            out[split] = ops.linear(Xd, Wd, bd).cpu().double()
+    finally:
+        ops.LINEAR_F16X3 = True
+    scale = X.double().abs() @ W.double().abs().t() + b.double().abs()      # sum |x_k w_k| + |b|: what rounding errors are relative to
+    err = {k: float(((v - ref).abs() / (scale + 1e-30)).max()) for k, v in out.items()}
+    assert err[True] <= 2.0 * err[False] + 2e-7 and err[True] < 1e-6, err
+    assert float(((out[True] - out[False]).abs() / (scale + 1e-30)).max()) < 1e-6
+    assert torch.equal(out[True][3], out[False][3])              # the zero row: bias only, exactly
+
+
 @pytest.mark.parametrize("n,F,out,bias", [(300, 96, 256, True), (1000, 256, 256, False), (129, 384, 384, True),
                                           (777, 4096, 256, True)])
 def test_linear_wide_fwd_bwd(ops, dev, n, F, out, bias):
