@@ -272,8 +272,11 @@ __device__ __forceinline__ void rows_batched(const int32_t* __restrict__ rowptr,
 
 // One launch covers both kinds of work: blocks [0, n_chunks) reduce one long-row chunk each (started
 // first: they are the longest dependency chains), blocks [n_chunks, ...) process 64 short rows each.
+#ifndef MMREC_SPMM_WAVES    // tools/spmm_rows_lab.py: minimum waves per SIMD the register allocator must leave room for (0: its choice)
+#define MMREC_SPMM_WAVES 0
+#endif
 template <int DCH, bool LG>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(
+__global__ __launch_bounds__(256, (DCH == 1 && !LG && MMREC_SPMM_WAVES) ? MMREC_SPMM_WAVES : 1) void spmm_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
     const float* __restrict__ vals, const float* __restrict__ X, RowEpilogue ep, int n_rows,
     int long_t, int rows_per_group, const int32_t* __restrict__ long_rows,

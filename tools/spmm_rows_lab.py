@@ -19,7 +19,8 @@ OUT = os.path.join(ROOT, "tools", "probe_libs")
 # (name, rpg for > 2^18 rows, RB, PF)
 VARIANTS = [("rpg1", 1, 0, 4), ("rpg2", 2, 0, 4), ("base_rpg4", 4, 0, 4), ("rpg8", 8, 0, 4),
             ("rb2_pf4", 2, 2, 4), ("rb2_pf8", 2, 2, 8), ("rb4_pf2", 4, 4, 2), ("rb4_pf4", 4, 4, 4), ("rb4_pf8", 4, 4, 8),
-            ("rb8_pf2", 8, 8, 2), ("rb8_pf4", 8, 8, 4)]
+            ("rb8_pf2", 8, 8, 2), ("rb8_pf4", 8, 8, 4), ("waves8", 4, 0, 4), ("waves8_rpg2", 2, 0, 4)]
+EXTRA = {"waves8": ["-DMMREC_SPMM_WAVES=8"], "waves8_rpg2": ["-DMMREC_SPMM_WAVES=8"]}
 
 
 def build():
@@ -30,7 +31,7 @@ def build():
         lib = os.path.join(OUT, "libspmm_rows_%s.so" % name)
         procs.append(subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                        "-munsafe-fp-atomics", "-DMMREC_SPMM_RPG(n)=((n) <= (1 << 18) ? 1 : %d)" % rpg,
-                                       "-DMMREC_SPMM_RB=%d" % rb, "-DMMREC_SPMM_PF=%d" % pf] + src + ["-o", lib]))
+                                       "-DMMREC_SPMM_RB=%d" % rb, "-DMMREC_SPMM_PF=%d" % pf] + EXTRA.get(name, []) + src + ["-o", lib]))
     assert all(p.wait() == 0 for p in procs)
     print("built", len(procs))
 
