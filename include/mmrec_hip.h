@@ -85,24 +85,6 @@ int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float
                        const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
                        float* partials, int32_t* long_tickets, mmrec_stream_t stream);
 
-/* ABI 8 -- mmrec_spmm_csr_f32 on a FEATURE SLICE (d = 8 / 16 / 32) with WINDOW-MAJOR LISTS: a second, build-time copy of the
- * SHORT rows' nonzeros (rows of at most long_row_threshold entries) that makes their gathers L2 resident -- a slice launch is
- * otherwise bound by one 128-B fabric line per nonzero.  Wave w owns rows [w rows_per_wave, (w + 1) rows_per_wave); its entries
- * are listed by (column window of ~2 MB of X, round, row), round j of a window holding the (j + 1)-th nonzero of every row that
- * has one there, each round padded to whole groups of 64 / (d / 4) entries (padding: col 0, val 0, row -1), so that the
- * entries of a group belong to different rows: wl_col / wl_val / wl_row [n_groups x group size] (row = row id minus the wave's
- * first row), wl_wave_ptr [n_waves + 1] group offsets.  The caller guarantees that the lists hold exactly the short rows'
- * nonzeros with every row's entries in CSR order (hip_ops.CsrGraph.window_lists builds them for column-sorted graphs, where
- * (window, round) order IS CSR order); then results are bit-identical to mmrec_spmm_csr_f32 on the slice and to the columns of
- * its d = 64 launch.  4 rows_per_wave d floats of LDS per workgroup (<= 64 KB).  Long rows: the plan arguments, as there. */
-int mmrec_spmm_csr_slice_windows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, float* Y,
-                                     const float* Z, const float* acc_in, float* acc_out, int32_t n_rows, int32_t d,
-                                     float alpha, float beta, float acc_scale, int32_t long_row_threshold,
-                                     const int32_t* long_rows, const int32_t* long_chunk_ptr, int32_t n_long,
-                                     int32_t n_chunks, float* partials, const int32_t* wl_col, const float* wl_val,
-                                     const int32_t* wl_row, const int32_t* wl_wave_ptr, int32_t n_waves,
-                                     int32_t rows_per_wave, mmrec_stream_t stream);
-
 /* One LayerGCN layer in one launch (layergcn.py:131-135): y = A x ; w[row] = cosine_similarity(y[row], ego[row]) with
  * eps 1e-8 per norm ; scaled = w * y (the next layer's input) ; acc_out = acc_in + scaled (acc_in NULL: acc_out = scaled;
  * acc_out NULL: no sum).  Y (the unscaled product, needed by the backward) may be NULL.  d must be 64.  Plan arguments

@@ -26,8 +26,6 @@ SIGNATURES = {
     "mmrec_error_string": (c_char_p, [c_int32]),
     "mmrec_spmm_csr_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_float,
                                      c_float, c_float, c_int32, _P, _P, c_int32, c_int32, _P, _P, _P]),
-    "mmrec_spmm_csr_slice_windows_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_float, c_float, c_float,
-                                                   c_int32, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, _P]),
     "mmrec_spmm_csr_f32_layergcn": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
                                               _P, _P, c_int32, c_int32, _P, _P, _P]),
     "mmrec_spmm_plan_count": (c_int32, [_P, c_int32, c_int32, _P, _P]),

@@ -466,7 +466,7 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     if (narrow)
         return spmm_narrow_launch(rowptr, colidx, vals, X, Y, Z, acc_in, acc_out, n_rows, d, alpha, beta, acc_scale,
                                   n_long > 0 ? long_row_threshold : INT32_MAX, long_rows, long_chunk_ptr, n_long,
-                                  n_long > 0 ? n_chunks : 0, partials, nullptr, mmrec_stream(stream));
+                                  n_long > 0 ? n_chunks : 0, partials, mmrec_stream(stream));
     RowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale, nullptr, nullptr, nullptr};
     hipStream_t s = mmrec_stream(stream);
     // small (cache-resident, latency-bound) graphs: one row per 16-lane group; large graphs: four
@@ -489,29 +489,6 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
     }
 #undef MMREC_SPMM_CASE
     MMREC_RETURN_LAUNCH_STATUS();
-}
-
-// mmrec_spmm_csr_f32 on a feature slice (d = 8 / 16 / 32) with WINDOW-MAJOR LISTS of the short rows' nonzeros (a second,
-// build-time copy: include/mmrec_hip.h): their gathers hit L2 instead of costing a fabric line each.  Same results bit for bit.
-extern "C" int mmrec_spmm_csr_slice_windows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
-                                                float* Y, const float* Z, const float* acc_in, float* acc_out, int32_t n_rows,
-                                                int32_t d, float alpha, float beta, float acc_scale, int32_t long_row_threshold,
-                                                const int32_t* long_rows, const int32_t* long_chunk_ptr, int32_t n_long,
-                                                int32_t n_chunks, float* partials, const int32_t* wl_col, const float* wl_val,
-                                                const int32_t* wl_row, const int32_t* wl_wave_ptr, int32_t n_waves,
-                                                int32_t rows_per_wave, mmrec_stream_t stream) {
-    if (d != 8 && d != 16 && d != 32) return MMREC_ERR_UNSUPPORTED;
-    if (n_rows < 0 || n_long < 0 || n_chunks < 0 || long_row_threshold < 0 || n_waves < 0) return MMREC_ERR_BAD_ARG;
-    if (n_rows == 0) return 0;
-    if (!rowptr || !X || (!Y && !acc_out) || (acc_out && !acc_in) || Y == X) return MMREC_ERR_BAD_ARG;
-    if (n_long > 0 && (!long_rows || !long_chunk_ptr || !partials || n_chunks <= 0)) return MMREC_ERR_BAD_ARG;
-    if (!wl_col || !wl_val || !wl_row || !wl_wave_ptr || rows_per_wave <= 0 || (long)n_waves * rows_per_wave < n_rows)
-        return MMREC_ERR_BAD_ARG;
-    if ((size_t)4 * (rows_per_wave + 1) * d * sizeof(float) > 64 * 1024) return MMREC_ERR_UNSUPPORTED;   // the workgroup's accumulators (LDS)
-    const NarrowWindowLists wl{wl_col, wl_val, wl_row, wl_wave_ptr, n_waves, rows_per_wave};
-    return spmm_narrow_launch(rowptr, colidx, vals, X, Y, Z, acc_in, acc_out, n_rows, d, alpha, beta, acc_scale,
-                              n_long > 0 ? long_row_threshold : INT32_MAX, long_rows, long_chunk_ptr, n_long,
-                              n_long > 0 ? n_chunks : 0, partials, &wl, mmrec_stream(stream));
 }
 
 // One LayerGCN layer in ONE launch: y = A x, w = cos(y, ego) per row, scaled = w y, acc_out = acc_in + scaled

@@ -163,100 +163,17 @@ __global__ __launch_bounds__(256) void spmm_narrow_long_reduce_kernel(
     }
 }
 
-// ---- window-major lists: the short rows' gathers made L2 resident ---------------------------------------------------------
-// A slice launch is bound by 128-B fabric lines, about one per nonzero (L2 hit rate 29 % at config 5: the 48 MB slice of X is
-// 12 x an XCD's L2).  For graphs whose rows are column-sorted the caller hands over a SECOND COPY of the short rows' nonzeros
-// (hip_ops.CsrGraph.window_lists, built once per graph and slice width): a wave owns `rpw` consecutive rows, and its nonzeros
-// are listed by (column WINDOW of ~2 MB of X, round, row) -- round j of a window holds the (j + 1)-th nonzero of every row that
-// has one there, padded to whole groups of 64 / LPR entries, so the entries of one group belong to DIFFERENT rows.  The wave
-// keeps its rows' accumulators in LDS and walks its list group by group: one coalesced load of (col, val, row) triples, one
-// gather instruction with every lane useful, one conflict-free LDS read-modify-write.  All waves of a launch start together and
-// walk the windows in the same order at the same average pace, so the chip gathers from the same few MB of X at any time:
-// L2 hits instead of fabric lines.  A row's terms are still added in CSR order (windows ascend, rounds ascend, the wave's
-// LDS operations execute in order): the same fma chain, the same bits.  Long rows stay with the chunk blocks.
-template <int LPR>
-__global__ __launch_bounds__(256) void spmm_narrow_windows_kernel(
-    const int32_t* __restrict__ rowptr, const float* __restrict__ X, NarrowEpilogue ep, int n_rows, int long_t,
-    const int32_t* __restrict__ wl_col, const float* __restrict__ wl_val, const int32_t* __restrict__ wl_row,
-    const int32_t* __restrict__ wl_ptr, int n_waves, int rpw) {
-    extern __shared__ float4 s_acc[];                       // [4 waves][rpw + 1][LPR] (row rpw: scratch for padding entries)
-    constexpr int GS = 64 / LPR;                            // entries per group: one per lane sub-group
-    const int lane = threadIdx.x & 63, t = lane % LPR, p = lane / LPR, wv = threadIdx.x >> 6;
-    const int w = blockIdx.x * 4 + wv;
-    if (w >= n_waves) return;                               // (no workgroup-level synchronisation below)
-    float4* acc = s_acc + (size_t)wv * (rpw + 1) * LPR;
-    for (int e = lane; e < (rpw + 1) * LPR; e += 64) acc[e] = f4_zero();
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const float4* X4 = reinterpret_cast<const float4*>(X);
-    const int g0 = wl_ptr[w], g1 = wl_ptr[w + 1];
-    constexpr int U = 8;                                    // groups in flight
-    // software pipeline: while the U gathers of this step fly, the (col, val, row) triples of the next step are fetched; the
-    // LDS updates run in list order (a row's next term may sit in the next group; the wave's LDS operations execute in order)
-    int c[U], r[U];
-    float v[U];
-    auto fetch = [&](int g, int (&cc)[U], float (&vv)[U], int (&rr)[U]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = min(g + u, g1 - 1) * GS + p;      // (past the end: the last group again, its rows masked off)
-            cc[u] = __builtin_nontemporal_load(wl_col + e);
-            vv[u] = __builtin_nontemporal_load(wl_val + e);
-            const int row = __builtin_nontemporal_load(wl_row + e);
-            rr[u] = g + u < g1 ? row : -1;
-        }
-    };
-    if (g0 < g1) fetch(g0, c, v, r);
-    for (int g = g0; g < g1; g += U) {
-        float4 x[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = X4[(size_t)c[u] * LPR + t];
-        __builtin_amdgcn_sched_barrier(0);
-        int cn[U], rn[U];
-        float vn[U];
-        fetch(g + U < g1 ? g + U : g0, cn, vn, rn);         // (the last step re-reads the first groups: values unused)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                       // (padding entries update a scratch row past the wave's rows: no branch)
-            const int at = (r[u] >= 0 ? r[u] : rpw) * LPR + t;
-            acc[at] = f4_fma(v[u], x[u], acc[at]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            c[u] = cn[u];
-            v[u] = vn[u];
-            r[u] = g + U < g1 ? rn[u] : -1;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const int row0 = w * rpw;
-    for (int i = p; i < rpw; i += GS) {
-        const int row = row0 + i;
-        if (row >= n_rows) break;
-        if (rowptr[row + 1] - rowptr[row] > long_t) continue;           // a long row: the chunk blocks write it
-        store_row<LPR>(ep, row, t, acc[i * LPR + t]);
-    }
-}
-
 template <int LPR>
 void launch(hipStream_t s, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
             const NarrowEpilogue& ep, int n_rows, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr,
-            int n_long, int n_chunks, float* partials, const NarrowWindowLists* wl) {
+            int n_long, int n_chunks, float* partials) {
     constexpr int CPB = 16 / LPR, SPB = 256 / LPR;
+    const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
+    const int blocks = (n_rows + SPB * rows_per_group - 1) / (SPB * rows_per_group);
     const int chunk_blocks = (n_chunks + CPB - 1) / CPB;
-    if (wl) {
-        // long rows: their chunk blocks alone (no row blocks); short rows: the window-major lists
-        if (chunk_blocks > 0)
-            hipLaunchKernelGGL(spmm_narrow_rows_kernel<LPR>, dim3(chunk_blocks), dim3(256), 0, s, rowptr, colidx, vals, X, ep, 0,
-                               long_t, 1, long_rows, long_chunk_ptr, n_long, n_chunks, chunk_blocks, partials);
-        hipLaunchKernelGGL(spmm_narrow_windows_kernel<LPR>, dim3((wl->n_waves + 3) / 4), dim3(256),
-                           (size_t)4 * (wl->rows_per_wave + 1) * LPR * sizeof(float4), s, rowptr, X, ep, n_rows, long_t, wl->col, wl->val,
-                           wl->row, wl->wave_ptr, wl->n_waves, wl->rows_per_wave);
-    } else {
-        const int rows_per_group = n_rows <= (1 << 18) ? 1 : 4;
-        const int blocks = (n_rows + SPB * rows_per_group - 1) / (SPB * rows_per_group);
-        hipLaunchKernelGGL(spmm_narrow_rows_kernel<LPR>, dim3(blocks + chunk_blocks), dim3(256), 0, s, rowptr, colidx, vals, X,
-                           ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, n_chunks, chunk_blocks,
-                           partials);
-    }
+    hipLaunchKernelGGL(spmm_narrow_rows_kernel<LPR>, dim3(blocks + chunk_blocks), dim3(256), 0, s, rowptr, colidx, vals, X,
+                       ep, n_rows, long_t, rows_per_group, long_rows, long_chunk_ptr, n_long, n_chunks, chunk_blocks,
+                       partials);
     if (n_long > 0 && n_chunks > n_long)     // at least one row spans several chunks
         hipLaunchKernelGGL(spmm_narrow_long_reduce_kernel<LPR>, dim3((n_long + CPB - 1) / CPB), dim3(256), 0, s, long_rows,
                            long_chunk_ptr, n_long, partials, ep);
@@ -267,17 +184,17 @@ void launch(hipStream_t s, const int32_t* rowptr, const int32_t* colidx, const f
 int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, float* Y,
                        const float* Z, const float* acc_in, float* acc_out, int n_rows, int d, float alpha, float beta,
                        float acc_scale, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr, int n_long,
-                       int n_chunks, float* partials, const NarrowWindowLists* wl, hipStream_t s) {
+                       int n_chunks, float* partials, hipStream_t s) {
     const NarrowEpilogue ep{Z, Y, acc_in, acc_out, alpha, Z ? beta : 0.f, acc_scale};
     switch (d) {
         case 8:
-            launch<2>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials, wl);
+            launch<2>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials);
             break;
         case 16:
-            launch<4>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials, wl);
+            launch<4>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials);
             break;
         case 32:
-            launch<8>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials, wl);
+            launch<8>(s, rowptr, colidx, vals, X, ep, n_rows, long_t, long_rows, long_chunk_ptr, n_long, n_chunks, partials);
             break;
         default:
             return MMREC_ERR_UNSUPPORTED;

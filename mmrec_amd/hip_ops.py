@@ -21,8 +21,6 @@ EMB_DIM = 64
 # products per 16 k; as accurate against float64 as the fp32-MFMA kernel, which is bound by the 1/16-rate fp32 matrix pipe and
 # not by the stream of X).  Domain |x|, |w| < 32768.  False (config `hip_linear_split: False`): the fp32 kernel.
 LINEAR_F16X3 = True
-SLICE_WINDOWS = True                 # feature-slice launches on big column-sorted graphs use window-major lists (A/B switch)
-SLICE_WINDOW_BYTES = 2 << 20         # bytes of X rows per column window (half an XCD's L2)
 SLICE_WIDTHS = (8, 16, 32)    # one feature slice of a 64-wide table: 64 / P columns per rank of the feature-sliced layout (csrc/spmm_narrow.hip)
 SPMM_CHUNK = 512
 LONG_ROW_DEFAULT = None    # by graph size, see default_long_row_threshold
@@ -122,7 +120,6 @@ class CsrGraph:
         self.long_row_threshold = int(default_long_row_threshold(self.n_cols) if long_row_threshold is None
                                       else long_row_threshold)
         self._t = self if symmetric else None
-        self._cols_sorted, self._wlists = None, {}
         self._plan(rowptr_host)
 
     # -- plan: rows longer than the threshold are cut into fixed-size chunks (host side, C helper)
@@ -165,76 +162,6 @@ class CsrGraph:
                 except RuntimeError:
                     pass                         # (a faulted device: nothing more will run on it anyway)
             raise
-
-    # -- window-major lists for the feature-slice launches (csrc/spmm_narrow.hip: spmm_narrow_windows_kernel)
-    @property
-    def cols_sorted(self):
-        """every row's nonzeros in ascending column order (get_norm_adj_mat's graphs are: freedom.py:102-126; the per-epoch
-        pruned graph keeps the multinomial draw's order and is not).  One device reduction, cached."""
-        if self._cols_sorted is None:
-            if self.nnz < 2:
-                self._cols_sorted = True
-            else:
-                ok = self.colidx[1:] >= self.colidx[:-1]
-                starts = self.rowptr[1:-1].long()                     # first entry of rows 1 .. n-1: a new row may start lower
-                starts = starts[(starts > 0) & (starts < self.nnz)]
-                ok[starts - 1] = True
-                self._cols_sorted = bool(ok.all())
-        return self._cols_sorted
-
-    def window_lists(self, d):
-        """The second copy of the short rows' nonzeros a feature-slice launch wants on big column-sorted graphs (None
-        otherwise): (col, val, row, wave_ptr, n_waves, rows_per_wave) device tensors, built once per slice width on the host
-        (a stable sort of the short rows' entries by (wave, column window, round); integer work, seconds at 20M nonzeros).
-        Rows are column-sorted, so (window, round) order IS a row's CSR order: the launch adds the same terms in the same order."""
-        if d in self._wlists:
-            return self._wlists[d]
-        out = None
-        x_bytes = self.n_cols * d * 4
-        if SLICE_WINDOWS and self.n_rows > (1 << 18) and x_bytes > (8 << 20) and self.cols_sorted:
-            lpr = d // 4
-            gs, rpw = 64 // lpr, 2048 // d                             # entries per group; rows per wave (8 KB of LDS accumulators)
-            blk = max(1, SLICE_WINDOW_BYTES // (4 * d))                # rows of X per column window
-            rp = self.rowptr_host.astype(np.int64)
-            deg = np.diff(rp)
-            ci = self.colidx.cpu().numpy().astype(np.int64)
-            va = self.vals.cpu().numpy()
-            rows = np.repeat(np.arange(self.n_rows, dtype=np.int64), deg)
-            keep = (deg <= self.long_row_threshold)[rows] if self.n_long > 0 else np.ones(rows.shape[0], dtype=bool)
-            r, c, v = rows[keep], ci[keep], va[keep]
-            n_win = (self.n_cols + blk - 1) // blk
-            key = r * n_win + c // blk                                 # non-decreasing in CSR order (rows ascend, columns ascend)
-            first = np.concatenate([[True], key[1:] != key[:-1]]) if key.shape[0] else np.zeros(0, dtype=bool)
-            start = np.maximum.accumulate(np.where(first, np.arange(key.shape[0]), 0)) if key.shape[0] else key
-            rnd = np.arange(key.shape[0]) - start                      # round = rank inside the (row, window) run
-            wave = r // rpw
-            n_waves = (self.n_rows + rpw - 1) // rpw
-            # segment = (wave, window, round); entries of a segment are distinct rows; segments padded to whole groups
-            max_rnd = int(rnd.max()) + 1 if rnd.shape[0] else 1
-            seg = (wave * n_win + c // blk) * max_rnd + rnd
-            order = np.argsort(seg, kind="stable")                     # stable: rows ascend inside a segment
-            seg_s = seg[order]
-            sfirst = np.concatenate([[True], seg_s[1:] != seg_s[:-1]]) if seg_s.shape[0] else np.zeros(0, dtype=bool)
-            seg_id = np.cumsum(sfirst) - 1
-            seg_len = np.bincount(seg_id) if seg_s.shape[0] else np.zeros(0, dtype=np.int64)
-            seg_pad = (seg_len + gs - 1) // gs * gs
-            seg_off = np.concatenate([[0], np.cumsum(seg_pad)])
-            pos_in = np.arange(seg_s.shape[0]) - np.concatenate([[0], np.cumsum(seg_len)])[seg_id] if seg_s.shape[0] else seg_s
-            dst = seg_off[seg_id] + pos_in
-            total = int(seg_off[-1])
-            wl_col = np.zeros(max(total, gs), dtype=np.int32)
-            wl_val = np.zeros(max(total, gs), dtype=np.float32)
-            wl_row = np.full(max(total, gs), -1, dtype=np.int32)
-            wl_col[dst], wl_val[dst], wl_row[dst] = c[order], v[order], (r[order] - wave[order] * rpw)
-            seg_wave = (seg_s[sfirst] // max_rnd) // n_win if seg_s.shape[0] else np.zeros(0, dtype=np.int64)
-            groups_per_wave = np.bincount(seg_wave, weights=seg_pad // gs, minlength=n_waves).astype(np.int64)
-            wave_ptr = np.concatenate([[0], np.cumsum(groups_per_wave)]).astype(np.int32)
-            dev = self.rowptr.device
-            out = (torch.from_numpy(wl_col).to(dev), torch.from_numpy(wl_val).to(dev), torch.from_numpy(wl_row).to(dev),
-                   torch.from_numpy(wave_ptr).to(dev), int(n_waves), int(rpw))
-            self.window_fill = float(r.shape[0]) / max(total, 1)        # useful entries per slot (diagnostic)
-        self._wlists[d] = out
-        return out
 
     def partials_for(self, d):
         """long-row workspace (n_chunks x d fp32), allocated once per embedding width"""
@@ -394,13 +321,6 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
             _chk(t, torch.float32, nm, 2)
             if t.shape[0] < g.n_rows or t.shape[1] != d:
                 raise _lib.MMRecHipError("%s must be [>=%d, %d]" % (nm, g.n_rows, d))
-    wl = g.window_lists(d) if d in SLICE_WIDTHS else None
-    if wl is not None:         # a feature slice of a big column-sorted graph: the short rows through their window-major lists
-        g.checked(lib.mmrec_spmm_csr_slice_windows_f32(
-            _p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Y), _p(Z), _p(acc_in), _p(acc_out), g.n_rows, d, float(alpha),
-            float(beta), float(acc_scale), g.long_row_threshold, _p(g.long_rows), _p(g.long_chunk_ptr), g.n_long, g.n_chunks,
-            _p(g.partials_for(d)), _p(wl[0]), _p(wl[1]), _p(wl[2]), _p(wl[3]), wl[4], wl[5], _stream()), "spmm_csr_slice_windows_f32")
-        return Y if Y is not None else acc_out
     g.checked(lib.mmrec_spmm_csr_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Y), _p(Z),
                                      _p(acc_in), _p(acc_out), g.n_rows, d, float(alpha),
                                      float(beta), float(acc_scale), g.long_row_threshold,

@@ -138,8 +138,7 @@ def test_spmm_feature_slices_equal_the_d64_launch_bitwise(ops, dev, n_rows, thr,
     contiguous) through mmrec_spmm_csr_f32 one after the other == the columns of the d = 64 launch BIT FOR BIT -- short
     rows, empty rows, single-chunk and multi-chunk long rows (both sides of the chunk size), both row-finish forms of the
     d = 64 kernel (last-arriver up to 2^18 rows, two launches above), plain and full epilogue (alpha, beta Z, running sum);
-    both slice kernels: the row-per-sub-group launch and, on big column-sorted graphs, the window-major lists with LDS
-    accumulators (spmm_narrow_windows_kernel; 1.1M rows = more waves than are resident at once)."""
+    random and column-sorted rows, up to 1.1M rows."""
     rng = np.random.default_rng(n_rows)
     n_cols = n_rows if n_rows > 1000 else 500
     degs = rng.integers(0, 40, n_rows)
@@ -150,8 +149,6 @@ def test_spmm_feature_slices_equal_the_d64_launch_bitwise(ops, dev, n_rows, thr,
         idx, val = idx[:, o], val[o]
     g = ops.CsrGraph.from_coo_host(idx, val, n_rows, n_cols, dev, long_row_threshold=thr)
     assert g.n_long > 0 and g.n_chunks > g.n_long
-    # big column-sorted graphs: the slice launches go through the window-major lists (spmm_narrow_windows_kernel)
-    assert (g.window_lists(8) is not None) == (sorted_cols and n_rows > (1 << 18))
     X = D(rng.standard_normal((n_cols, 64)).astype(np.float32), dev)
     Z = D(rng.standard_normal((n_rows, 64)).astype(np.float32), dev)
     A0 = D(rng.standard_normal((n_rows, 64)).astype(np.float32), dev)

@@ -38,10 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--out", default="")
-    ap.add_argument("--window-mb", type=float, default=0.0, help="bytes of X per column window of the window-major lists (MB)")
     args = ap.parse_args()
-    if args.window_mb:
-        hip_ops.SLICE_WINDOW_BYTES = int(args.window_mb * (1 << 20))
     dev = torch.device("cuda", 0)
     nu, ni, eu, ei = synth.shaped_edges("c5", seed=0)
     r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
@@ -63,20 +60,11 @@ def main():
     out = {}
     for name, (g, n_x) in graphs.items():
         t = {d: time_layer(g, n_x, d, args.reps) for d in (64, 32, 16, 8)}
-        plain = None
-        if g.window_lists(8) is not None:      # A/B: window-major lists (default on big column-sorted graphs) vs the plain slice kernel
-            hip_ops.SLICE_WINDOWS = False
-            g._wlists = {}
-            plain = {d: time_layer(g, n_x, d, args.reps) for d in (32, 16, 8)}
-            hip_ops.SLICE_WINDOWS = True
-            g._wlists = {}
         alg = {d: ((8 + 4 * d) * g.nnz + (4 + 4 * d) * g.n_rows) / 1e9 for d in t}
         out[name] = {"nnz": g.nnz, "rows": g.n_rows, "ms_per_layer": {str(d): round(x, 4) for d, x in t.items()},
                      "implied_speedup": {str(64 // d): round(t[64] / t[d], 2) for d in (32, 16, 8)},
                      "algorithmic_GB": {str(d): round(x, 3) for d, x in alg.items()},
-                     "algorithmic_TBps": {str(d): round(alg[d] / t[d], 2) for d in t},
-                     "window_lists": plain is not None, "window_fill": getattr(g, "window_fill", None),
-                     "ms_per_layer_plain_slice_kernel": None if plain is None else {str(d): round(x, 4) for d, x in plain.items()}}
+                     "algorithmic_TBps": {str(d): round(alg[d] / t[d], 2) for d in t}}
         print(name, json.dumps(out[name]), flush=True)
     if args.out:
         with open(args.out, "w") as f:
