@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 8
+#define MMREC_ABI_VERSION 9
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -140,6 +140,18 @@ int mmrec_bpr_bwd_f32(const float* U, const float* P, const float* N, const int6
                       const int64_t* pos, const int64_t* neg, int32_t batch, int32_t d,
                       const float* coef, const float* grad_scalar, float scale, float* dU, float* dP,
                       float* dN, mmrec_stream_t stream);
+
+/* The same loss on a COLUMN SLICE of the tables (feature-sliced multi-GPU layout, SURVEY.md 8e: a rank holds d / P = 8, 16
+ * or 32 columns of every table; whole tables, d a multiple of 64, work too).  <u, p> and <u, n> of freedom.py:183-184 are sums
+ * over the ranks of partial dot products: mmrec_bpr_dots_f32 writes dots[0..B) = <u, p>, dots[B..2B) = <u, n> over the
+ * columns given; the caller sums `dots` over the ranks (one all-reduce of 2B floats per term), then
+ * mmrec_bpr_loss_from_dots_f32 computes loss_out / coef from the sums exactly as mmrec_bpr_fwd_f32 does (same workspace
+ * size), and mmrec_bpr_bwd_f32 takes that coef on the rank's own columns (d = 8 / 16 / 32 accepted there as well). */
+int mmrec_bpr_dots_f32(const float* U, const float* P, const float* N, const int64_t* users,
+                       const int64_t* pos, const int64_t* neg, int32_t batch, int32_t d, float* dots,
+                       mmrec_stream_t stream);
+int mmrec_bpr_loss_from_dots_f32(const float* dots, int32_t batch, int32_t variant, float scale,
+                                 float* loss_out, float* coef, void* workspace, mmrec_stream_t stream);
 
 /* Sum of squared L2 norms of gathered rows: out[0] = sum_b ||E[ids[b]]||^2 (fixed-order tree).
  * replaces the gathers + norms of EmbLoss / L2Loss -- common/loss.py:46-51,58-62 as used at

@@ -45,6 +45,49 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(
     }
 }
 
+// The two halves of bpr_fwd_kernel for a COLUMN SLICE of the tables (feature-sliced multi-GPU layout): a rank
+// holds d / P columns, <u, p> and <u, n> are sums over the ranks of these partial dot products (one small all-reduce by the
+// caller), then the loss and d loss / d score are computed from the summed scores, replicated.
+__global__ __launch_bounds__(256) void bpr_dots_kernel(
+    const float* __restrict__ U, const float* __restrict__ P, const float* __restrict__ N,
+    const int64_t* __restrict__ users, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int batch, int d4,
+    float* __restrict__ dots) {
+    const int lane16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= batch) return;
+    const size_t iu = (size_t)users[b] * d4, ip = (size_t)pos[b] * d4, in = (size_t)neg[b] * d4;
+    float pp = 0.f, nn = 0.f;
+    for (int c = lane16; c < d4; c += 16) {      // slices of 8 / 16 / 32 columns: 2 / 4 / 8 live lanes, the rest add zeros
+        const float4 u = reinterpret_cast<const float4*>(U)[iu + c];
+        pp += f4_dot(u, reinterpret_cast<const float4*>(P)[ip + c]);
+        nn += f4_dot(u, reinterpret_cast<const float4*>(N)[in + c]);
+    }
+    const float ps = row16_sum(pp);
+    const float ns = row16_sum(nn);
+    if (lane16 == 0) {
+        dots[b] = ps;
+        dots[batch + b] = ns;
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_from_dots_kernel(const float* __restrict__ dots, int batch, int variant,
+                                                            float* __restrict__ loss_i, float* __restrict__ coef) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= batch) return;
+    const float x = dots[b] - dots[batch + b];
+    float l, c;
+    if (variant == MMREC_BPR_LOGSIG) {
+        l = neg_logsigmoid(x);
+        c = -1.0f / (1.0f + expf(x));
+    } else {
+        const float s = 1.0f / (1.0f + expf(-x));
+        l = -logf(1e-10f + s);
+        c = -(s * (1.0f - s)) / (1e-10f + s);
+    }
+    loss_i[b] = l;
+    coef[b] = c;
+}
+
 // out[0] = scale * sum(v[0..n)) ; single block, fixed-order (strided partial sums + LDS tree).
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ v, int n,
                                                          float scale, float* __restrict__ out) {
@@ -228,12 +271,41 @@ extern "C" int mmrec_bpr_fwd_f32(const float* U, const float* P, const float* N,
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
+// rows of a feature slice (8 / 16 / 32 floats) or of whole tables (64 k floats)
+static bool bpr_slice_width(int d) { return d == 8 || d == 16 || d == 32 || (d > 0 && d % MMREC_EMB_DIM == 0); }
+
+extern "C" int mmrec_bpr_dots_f32(const float* U, const float* P, const float* N, const int64_t* users, const int64_t* pos,
+                                  const int64_t* neg, int32_t batch, int32_t d, float* dots, mmrec_stream_t stream) {
+    if (!bpr_slice_width(d)) return MMREC_ERR_UNSUPPORTED;
+    if (batch < 0) return MMREC_ERR_BAD_ARG;
+    if (batch == 0) return 0;
+    if (!U || !P || !N || !users || !pos || !neg || !dots) return MMREC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bpr_dots_kernel, dim3((batch + 15) / 16), dim3(256), 0, mmrec_stream(stream), U, P, N, users, pos, neg,
+                       batch, d / 4, dots);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_bpr_loss_from_dots_f32(const float* dots, int32_t batch, int32_t variant, float scale, float* loss_out,
+                                            float* coef, void* workspace, mmrec_stream_t stream) {
+    if (variant != MMREC_BPR_LOGSIG && variant != MMREC_BPR_GAMMA) return MMREC_ERR_BAD_ARG;
+    if (batch < 0 || !loss_out) return MMREC_ERR_BAD_ARG;
+    hipStream_t s = mmrec_stream(stream);
+    if (batch > 0) {
+        if (!dots || !coef || !workspace) return MMREC_ERR_BAD_ARG;
+        hipLaunchKernelGGL(bpr_from_dots_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, dots, batch, variant,
+                           static_cast<float*>(workspace), coef);
+    }
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, static_cast<const float*>(workspace), batch, scale,
+                       loss_out);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int mmrec_bpr_bwd_f32(const float* U, const float* P, const float* N,
                                  const int64_t* users, const int64_t* pos, const int64_t* neg,
                                  int32_t batch, int32_t d, const float* coef,
                                  const float* grad_scalar, float scale, float* dU, float* dP,
                                  float* dN, mmrec_stream_t stream) {
-    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;  // rows of 64, 128, ... floats
+    if (!bpr_slice_width(d)) return MMREC_ERR_UNSUPPORTED;  // rows of 64, 128, ... floats, or a slice of 8 / 16 / 32
     if (batch < 0) return MMREC_ERR_BAD_ARG;
     if (batch == 0) return 0;
     if (!U || !P || !N || !users || !pos || !neg || !coef || !grad_scalar) return MMREC_ERR_BAD_ARG;
@@ -297,7 +369,7 @@ __global__ __launch_bounds__(256) void scatter_rows_sorted_kernel(const int64_t*
 
 extern "C" int mmrec_scatter_add_rows_sorted_f32(const int64_t* order, const int64_t* ids, const float* rows, int32_t n,
                                                  int32_t d, float* out, mmrec_stream_t stream) {
-    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    if (!bpr_slice_width(d)) return MMREC_ERR_UNSUPPORTED;
     if (n < 0) return MMREC_ERR_BAD_ARG;
     if (n == 0) return 0;
     if (!order || !ids || !rows || !out) return MMREC_ERR_BAD_ARG;

@@ -613,7 +613,7 @@ class _BprLossShared(torch.autograd.Function):
     term and their sums."""
 
     @staticmethod
-    def forward(ctx, U, users, variant, scale, n_terms, joint, *flat):
+    def forward(ctx, U, users, variant, scale, n_terms, joint, sum_over_ranks, *flat):
         lib = _lib.load()
         ctx.joint = bool(joint)
         U = _chk(U.contiguous(), torch.float32, "U", 2)
@@ -621,17 +621,35 @@ class _BprLossShared(torch.autograd.Function):
         B, dev = users.numel(), U.device
         tables, ids, coefs, losses = [], [], [], []
         ws = _ws(lib.mmrec_bpr_workspace_bytes(B), dev)
+        d = U.shape[1]
+        sliced = sum_over_ranks is not None
+        if sliced:          # column slices: partial <u, p>, <u, n> of every term, ONE sum over the ranks, then the losses
+            dots = torch.empty((n_terms, 2, max(B, 1)), dtype=torch.float32, device=dev)
         for t in range(n_terms):
             I, pos, neg = flat[3 * t], flat[3 * t + 1], flat[3 * t + 2]
             I = _chk(I.contiguous(), torch.float32, "I", 2)
             _chk(pos, torch.int64, "pos", 1), _chk(neg, torch.int64, "neg", 1)
-            if U.shape[1] != I.shape[1] or U.shape[1] % EMB_DIM:
-                raise _lib.MMRecHipError("U and I need the same row width, a multiple of %d" % EMB_DIM)
+            if d != I.shape[1] or (d % EMB_DIM and not (sliced and d in SLICE_WIDTHS)):
+                raise _lib.MMRecHipError("U and I need the same row width, a multiple of %d%s" %
+                                         (EMB_DIM, " or a slice of 8 / 16 / 32 columns" if sliced else ""))
+            tables.append(I), ids.extend((pos, neg))
+            if sliced:
+                _lib.check(lib.mmrec_bpr_dots_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), B, d, _p(dots[t]),
+                                                  _stream()), "bpr_dots")
+                continue
             loss = torch.empty((), dtype=torch.float32, device=dev)
             coef = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
-            _lib.check(lib.mmrec_bpr_fwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), B, U.shape[1],
+            _lib.check(lib.mmrec_bpr_fwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), B, d,
                                              int(variant), float(scale), _p(loss), _p(coef), _p(ws), _stream()), "bpr_fwd")
-            tables.append(I), ids.extend((pos, neg)), coefs.append(coef), losses.append(loss)
+            coefs.append(coef), losses.append(loss)
+        if sliced:
+            sum_over_ranks(dots)                                  # in place
+            for t in range(n_terms):
+                loss = torch.empty((), dtype=torch.float32, device=dev)
+                coef = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+                _lib.check(lib.mmrec_bpr_loss_from_dots_f32(_p(dots[t]), B, int(variant), float(scale), _p(loss), _p(coef),
+                                                            _p(ws), _stream()), "bpr_loss_from_dots")
+                coefs.append(coef), losses.append(loss)
         ctx.save_for_backward(U, users, *tables, *ids, *coefs)
         ctx.scale, ctx.n_terms = float(scale), n_terms
         return tuple(losses)
@@ -644,7 +662,7 @@ class _BprLossShared(torch.autograd.Function):
         U, users = saved[0], saved[1]
         tables, ids, coefs = saved[2:2 + n], saved[2 + n:2 + 3 * n], saved[2 + 3 * n:]
         dU = dI0 = None
-        if ctx.joint and ctx.needs_input_grad[0] and ctx.needs_input_grad[6]:
+        if ctx.joint and ctx.needs_input_grad[0] and ctx.needs_input_grad[7]:
             # the gradients of U and of the first item table as adjacent row blocks of one zero-filled buffer: when both
             # came out of lightgcn_mean_parts, its backward takes the buffer as the gradient of its output, copy-free
             both = torch.zeros((U.shape[0] + tables[0].shape[0], U.shape[1]), dtype=U.dtype, device=U.device)
@@ -654,7 +672,7 @@ class _BprLossShared(torch.autograd.Function):
         out = []
         for t in range(n):
             I, pos, neg = tables[t], ids[2 * t], ids[2 * t + 1]
-            need_i = ctx.needs_input_grad[6 + 3 * t]
+            need_i = ctx.needs_input_grad[7 + 3 * t]
             own = dI0 if t == 0 and dI0 is not None else None
             if gs[t] is None or (dU is None and not need_i):
                 out.extend(((own if own is not None else torch.zeros_like(I)) if need_i else None, None, None))
@@ -667,16 +685,19 @@ class _BprLossShared(torch.autograd.Function):
                 _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), users.numel(), U.shape[1],
                                                  _p(coefs[t]), _p(g), ctx.scale, _p(dU), _p(dI), _p(dI), _stream()), "bpr_bwd")
             out.extend((dI, None, None))
-        return (dU, None, None, None, None, None) + tuple(out)
+        return (dU, None, None, None, None, None, None) + tuple(out)
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False):
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None):
     """[bpr_loss(U, I_t, users, pos_t, neg_t) for (I_t, pos_t, neg_t) in terms] with one shared gradient buffer for U;
-    joint_grad: the gradient of the FIRST term's table is the row block right after U's in the same buffer"""
+    joint_grad: the gradient of the FIRST term's table is the row block right after U's in the same buffer.
+    sum_over_ranks (feature-sliced layout): U and the tables are this rank's COLUMNS (8 / 16 / 32 of them, or whole rows);
+    the callable sums the [terms, 2, B] partial dot products over the ranks in place (one all-reduce), the losses come out
+    replicated and every rank's backward scatters into its own columns -- the same kernels, no collective."""
     B = users.numel()
     scale = 1.0 / max(B, 1) if reduction == "mean" else 1.0
     flat = [x for term in terms for x in term]
-    return _BprLossShared.apply(U, users, variant, scale, len(terms), joint_grad, *flat)
+    return _BprLossShared.apply(U, users, variant, scale, len(terms), joint_grad, sum_over_ranks, *flat)
 
 
 def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):

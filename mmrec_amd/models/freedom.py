@@ -456,23 +456,6 @@ class RowShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
 # ------------------------------------------------------------------------------------------------------------------
 # n_gpus > 1, FEATURE-sliced (config `dist_layout: dslice`; the default at 2 / 4 / 8 ranks)
 # ------------------------------------------------------------------------------------------------------------------
-class _AllReduceSum(torch.autograd.Function):
-    """sum over ranks of rank-local partial results whose CONSUMER is replicated (every rank computes the same loss from the
-    sum): forward all-reduce; the incoming gradient is the same on every rank and is each rank's own partial's gradient."""
-
-    @staticmethod
-    def forward(ctx, x, group, multi):
-        out = x.contiguous().clone()
-        if multi:
-            import torch.distributed as tdist
-            tdist.all_reduce(out, op=tdist.ReduceOp.SUM, group=group)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        return g, None, None
-
-
 class _TakeColumns(torch.autograd.Function):
     """this rank's column slice of a REPLICATED [B, d] matrix whose producer needs the gradient of ALL columns (the owner of
     a projected feature row back-propagates through its whole row): backward places the rank's [B, d / P] gradient at its
@@ -491,17 +474,6 @@ class _TakeColumns(torch.autograd.Function):
             import torch.distributed as tdist
             tdist.all_reduce(full, op=tdist.ReduceOp.SUM, group=ctx.group)
         return full, None, None, None, None
-
-
-def sliced_bpr_losses(ua_s, users, terms, group, multi):
-    """FREEDOM.bpr_loss (freedom.py:180-187) per term on COLUMN SLICES: every rank holds d / P columns of the user table and of
-    each term's table, <u, p> - <u, n> is the sum over ranks of the slices' partial dot products -- ONE all-reduce of
-    [terms, 2, B] floats per step (48 KB at B = 2048) -- and -mean(logsigmoid(.)) is computed replicated.  Backward needs no
-    collective: d loss / d score is the same on every rank and each rank differentiates its own columns."""
-    u = ua_s[users]
-    dots = torch.stack([torch.stack(((u * t[p]).sum(1), (u * t[n]).sum(1))) for t, p, n in terms])
-    dots = _AllReduceSum.apply(dots, group, multi)
-    return tuple(-torch.nn.functional.logsigmoid(dots[j, 0] - dots[j, 1]).mean() for j in range(len(terms)))
 
 
 class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
@@ -656,7 +628,14 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
             terms.append((self._owned_projection(self.text_embedding, self.text_trs, rows), lp, ln))
         if self.has_image:
             terms.append((self._owned_projection(self.image_embedding, self.image_trs, rows), lp, ln))
-        return _combine(sliced_bpr_losses(ua, users, terms, self.group, self.multi), self.has_text, self.reg_weight)
+        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, sum_over_ranks=self._sum_over_ranks),
+                        self.has_text, self.reg_weight)
+
+    def _sum_over_ranks(self, t):
+        """the layout's per-step exchange: the [terms, 2, B] partial dot products, summed in place"""
+        if self.multi:
+            import torch.distributed as tdist
+            tdist.all_reduce(t, op=tdist.ReduceOp.SUM, group=self.group)
 
     full_sort_topk = RowShardedFREEDOM.full_sort_topk        # users sharded over the ranks, replicated item table
 

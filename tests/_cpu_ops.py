@@ -162,8 +162,35 @@ def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):
     return per.mean() if reduction == "mean" else per.sum()
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False):
-    return tuple(bpr_loss(U, I, users, pos, neg, variant, reduction) for I, pos, neg in terms)
+class _SumOverRanks(torch.autograd.Function):
+    """the caller's in-place sum over ranks of partial results whose consumer is replicated: the incoming gradient is the same
+    on every rank and is each rank's own partial's gradient"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        out = x.contiguous().clone()
+        fn(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None):
+    if sum_over_ranks is None:
+        return tuple(bpr_loss(U, I, users, pos, neg, variant, reduction) for I, pos, neg in terms)
+    assert U.shape[1] % EMB_DIM == 0 or U.shape[1] in SLICE_WIDTHS, "slice width the kernels have"
+    _ids(users, "users")
+    u = U[users]
+    dots = torch.stack([torch.stack(((u * t[p]).sum(1), (u * t[n]).sum(1))) for t, p, n in terms])
+    dots = _SumOverRanks.apply(dots, sum_over_ranks)
+    out = []
+    for j in range(len(terms)):
+        x = dots[j, 0] - dots[j, 1]
+        per = -F.logsigmoid(x) if variant == BPR_LOGSIG else -torch.log(1e-10 + torch.sigmoid(x))
+        out.append(per.mean() if reduction == "mean" and users.numel() else per.sum())
+    return tuple(out)
 
 
 def infonce(E1, E2, ids, tau):

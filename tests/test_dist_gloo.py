@@ -505,6 +505,7 @@ def _worker_sliced_propagation(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import _cpu_ops
     _cpu_ops.install()
+    torch.set_num_threads(1)          # torch's CPU sparse product is only run-to-run bitwise with a fixed thread partition
     from mmrec_amd import hip_ops, synth
     nu, ni, eu, ei = 900, 400, *synth.powerlaw_edges(900, 400, 9000, seed=3)
     r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
@@ -539,8 +540,13 @@ def test_feature_sliced_propagation_equals_one_process_bitwise(tmp_path, cpu_ops
     g = hip_ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, "cpu", symmetric=True)
     gen = torch.Generator().manual_seed(0)
     E0, G = (torch.randn(n, 64, generator=gen) * 0.1).requires_grad_(), torch.randn(n, 64, generator=gen)
-    o = hip_ops.lightgcn_mean(g, E0, 3)
-    o.backward(G)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)          # as in the workers (the stand-in's sums depend on torch's thread partition)
+    try:
+        o = hip_ops.lightgcn_mean(g, E0, 3)
+        o.backward(G)
+    finally:
+        torch.set_num_threads(threads)
     assert torch.equal(got[0], o.detach())
     # (the torch-CPU stand-in's autograd blocks its sparse products by row width: its backward agrees to rounding only; the
     # HIP kernels' backward is bitwise too -- test_lightgcn_mean_on_feature_slices_forward_and_backward_bitwise, on the device)

@@ -403,6 +403,51 @@ def test_bpr_variants_with_duplicates(ops, dev, variant, reduction):
     close(Id.grad, I.grad, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sliced_shared_user_bpr_equals_the_full_width_op(ops, dev, world, variant):
+    """the sampled-scoring kernels on COLUMN SLICES (feature-sliced layout): `world` ranks simulated in one
+    process -- each slice's partial <u, p>, <u, n> (mmrec_bpr_dots_f32) against float64, their sum through
+    mmrec_bpr_loss_from_dots_f32 == the full-width fused op's losses, and the slices' backward (mmrec_bpr_bwd_f32 at
+    d = 64 / world) == the matching columns of its gradients.  Duplicate users / items in the batch on purpose."""
+    gen = torch.Generator().manual_seed(7 + world)
+    n_u, n_i, B, w = 500, 700, 333, 64 // world
+    U, I, T = (torch.randn(n, 64, generator=gen) * 0.4 for n in (n_u, n_i, 2 * B))
+    users, pos, neg = (torch.randint(0, n, (B,), generator=gen).to(dev) for n in (n_u // 3, n_i // 3, n_i))
+    lp = torch.arange(B, device=dev)
+    ln = lp + B
+
+    def run(cols, sum_fn):
+        u, i, t = (x[:, cols].contiguous().to(dev).requires_grad_() for x in (U, I, T))
+        ls = ops.bpr_losses_shared_users(u, users, [(i, pos, neg), (t, lp, ln)], variant, sum_over_ranks=sum_fn)
+        (ls[0] + 0.37 * ls[1]).backward()
+        return [x.detach().cpu() for x in ls], [x.grad.cpu() for x in (u, i, t)]
+
+    ref_l, ref_g = run(slice(0, 64), None)
+    slices = [slice(r * w, (r + 1) * w) for r in range(world)]
+    partial = []
+    for cols in slices:                                                  # pass 1: every rank's partial dot products
+        run(cols, lambda t: partial.append(t.clone()))
+        u64, i64, t64 = (x[:, cols].double() for x in (U, I, T))
+        uu = u64[users.cpu()]
+        want = torch.stack((torch.stack(((uu * i64[pos.cpu()]).sum(1), (uu * i64[neg.cpu()]).sum(1))),
+                            torch.stack(((uu * t64[:B]).sum(1), (uu * t64[B:]).sum(1)))))
+        close(partial[-1], want, rtol=1e-5, atol=1e-6)
+    total = partial[0].clone()
+    for x in partial[1:]:
+        total += x                                                       # what the all-reduce hands every rank
+    grads = []
+    for cols in slices:                                                  # pass 2: the replicated losses, the local backward
+        ls, gs = run(cols, lambda t: t.copy_(total))
+        for a, b in zip(ls, ref_l):
+            close(a, b, rtol=2e-6, atol=1e-7)
+        grads.append(gs)
+    for j in range(3):
+        close(torch.cat([g[j] for g in grads], 1), ref_g[j], rtol=1e-5, atol=1e-7)
+    with pytest.raises(Exception):                                       # a width no kernel has
+        run(slice(0, 24), lambda t: None)
+
+
 def test_shared_user_bpr_and_split_mean_match_the_separate_ops(ops, dev, golden):
     """FREEDOM's fused autograd nodes (one [n_users, d] gradient buffer for the three BPR terms; cat -> propagate -> split
     as one node) against the per-op composition with torch's cat / slices / adds around it and against the CPU oracle:

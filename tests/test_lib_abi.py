@@ -83,6 +83,13 @@ def test_argument_errors_without_gpu(lib):
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 65, None, None, None, 0, None) == 10001
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 5, None, None, None, 2, None) == 10001   # unknown flag
     assert lib.mmrec_linear_fwd_f32(None, None, None, None, 4, 6, 64, None, None) == 10002  # F % 4
+    # sampled scoring on a column slice: widths 8 / 16 / 32 / 64 k, nothing else
+    assert lib.mmrec_bpr_dots_f32(None, None, None, None, None, None, 5, 24, None, None) == 10002
+    assert lib.mmrec_bpr_dots_f32(None, None, None, None, None, None, 5, 16, None, None) == 10001
+    assert lib.mmrec_bpr_dots_f32(None, None, None, None, None, None, 0, 8, None, None) == 0            # empty batch
+    assert lib.mmrec_bpr_loss_from_dots_f32(None, 5, 7, 1.0, None, None, None, None) == 10001           # unknown variant
+    assert lib.mmrec_bpr_bwd_f32(None, None, None, None, None, None, 5, 40, None, None, 1.0, None, None, None, None) == 10002
+    assert lib.mmrec_bpr_bwd_f32(None, None, None, None, None, None, 5, 8, None, None, 1.0, None, None, None, None) == 10001
 
 
 def test_topk_workspace_covers_both_kd64_paths(lib):
