@@ -4,6 +4,8 @@
 
     python tools/topk_survivor_model.py c5        # E = A^3 X0 of the config-5 graph (what bench.py's c5_full_eval ranks)
     python tools/topk_survivor_model.py sports    # layer mean of a 2-layer propagation at Amazon-Sports shape
+    python tools/topk_survivor_model.py c5 tiles  # round 4: could pass 2 SKIP tiles?  share of (queries x candidates) tiles that
+                                                  # hold a survivor, and what a norm bound |q||c'| < thr would prune
 
 Round 3: at config 5 ONE candidate of norm 2.5 (median 0.11) sets eps, so ~120 candidates per query survive at
 stride 1 (63 without the margin) and ~245 at stride 2 -- more than the 256 slots the lists had for a third of the queries."""
@@ -121,5 +123,58 @@ def main(shape):
                   np.median(k + deg[qs]), (surv > 256).mean(), (surv > 512).mean()))
 
 
+def tiles(shape):
+    """Round-3 review, lever (ii): let pass 2 skip the MFMA tiles without a survivor.  A tile can only be skipped for ALL the
+    queries that share its products (32 per MFMA, 64 per wave, 256 per LDS tile); this prints the share of tiles that hold at
+    least one candidate >= thr for blocks of consecutive queries, with thr from the stride-2 bound as the kernels compute it --
+    and the share of candidates a Cauchy-Schwarz bound (|q| |c'| < thr, candidates sorted by norm) would let a block skip."""
+    nu, ni, eu, ei = synth.shaped_edges(shape, seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    A = sp.coo_matrix((v, (r, c)), shape=(nu + ni, nu + ni)).tocsr()
+    rng = np.random.default_rng(0)
+    E = rng.random((nu + ni, 64), dtype=np.float32) - 0.5
+    for _ in range(3):
+        E = A @ E
+    U, I = E[:nu], E[nu:]
+    mean = I.mean(0)
+    Ic = I - mean
+    cn = np.linalg.norm(Ic, axis=1)
+    tau, n_out = clip_threshold(cn) if ni >= 131072 else (np.inf, 0)
+    cm = min(cn.max(), tau)
+    Icc = Ic * np.minimum(1.0, tau / np.maximum(cn, 1e-30))[:, None]
+    deg = np.bincount(eu, minlength=nu)
+    k, n_ranges, S = 50, 16, 2 if ni >= 131072 else 1
+    n_stages = ni // 64
+    spr = (-(-((ni + 63) // 64) // n_ranges) + 3) // 4 * 4
+    share = {(32, 32): [], (32, 64): [], (64, 64): [], (256, 64): []}
+    prune, surv = {32: [], 64: [], 256: []}, []
+    for b0 in rng.integers(0, nu - 256, 6):
+        Sc = U[b0:b0 + 256] @ Icc.T                                            # [256, ni]
+        keep = np.zeros((256, n_stages * 64), dtype=bool)
+        rho = np.empty(256)
+        for j in range(256):
+            s, m, qn = Sc[j], int(deg[b0 + j]), np.linalg.norm(U[b0 + j])
+            eps = qn * (1.0e-3 * cm + 4e-6 * (cn.max() + np.linalg.norm(mean))) + 2.4e-7 * (qn + cm)
+            gm = np.full(32 * n_ranges, -np.inf)
+            for rg in range(n_ranges):
+                st = np.arange(rg * spr, min((rg + 1) * spr, n_stages))[::S]
+                if len(st):
+                    gm[rg * 32:(rg + 1) * 32] = s[st[:, None] * 64 + np.arange(64)[None, :]].reshape(len(st), 2, 32).max(axis=(0, 1))
+            thr = np.sort(gm)[::-1][min(k + m, gm.size) - 1] - 2 * eps
+            keep[j] = s[:n_stages * 64] >= thr
+            rho[j] = thr / max(qn, 1e-30)
+            surv.append(int(keep[j].sum()))
+        for (tq, tc) in share:
+            kk = keep.reshape(256 // tq, tq, n_stages * 64 // tc, tc).any(axis=(1, 3))
+            share[(tq, tc)].append(kk.mean())
+        for tq in prune:
+            prune[tq].append(np.mean([(cn < rho[a:a + tq].min()).mean() for a in range(0, 256, tq)]))
+    print("%s: survivors per query median %d; tiles with >= 1 survivor:" % (shape, np.median(surv)))
+    for (tq, tc), x in share.items():
+        print("   %3d queries x %2d candidates: %.3f" % (tq, tc, np.mean(x)))
+    print("   candidates with |q||c'| < thr for EVERY query of a block (prunable by a norm bound): " +
+          "  ".join("%d queries %.4f" % (tq, np.mean(x)) for tq, x in prune.items()))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "c5")
+    (tiles if len(sys.argv) > 2 and sys.argv[2] == "tiles" else main)(sys.argv[1] if len(sys.argv) > 1 else "c5")
