@@ -275,7 +275,7 @@ class Trainer(AbstractTrainer):
             why_dense = 'the model has no full_sort_topk'
         else:
             from mmrec_amd import hip_ops
-            if k > hip_ops.TOPK_MAX:             # torch.topk takes any k; the kernels 128 (64 below 4096 items: the call says so)
+            if k > hip_ops.TOPK_MAX:             # torch.topk takes any k; the kernels 128 (64 for row widths that are not a multiple of 32: the call says so)
                 why_dense = 'max(topk) = %d > %d' % (k, hip_ops.TOPK_MAX)
         if why_dense and strict and self.fused_eval:
             raise RuntimeError('strict_fused_eval: the fused evaluation cannot serve this run (%s)' % why_dense)

@@ -501,13 +501,24 @@ __global__ __launch_bounds__(256) void select_topk_kernel(
         // ---- sort list[0..cnt): best 64 in y0 (rank = lane), next 64 in y1
         const int n = cnt;
         auto fetch = [&](int e) -> Cand { return e < n ? unpack_cand(list[e]) : Cand{-INFINITY, INT_MAX}; };
-        Cand y0 = fetch(lane), y1;
-        int pos = 64;
-        do {   // more than 128 entries (rare): fold the rest in, 64 at a time
-            y1 = fetch(pos + lane);
-            bitonic128(y0, y1, lane);
+        // more than 128 entries (rare): the rest is folded in 64 at a time.  k <= 64 needs the best 64 only: the next chunk
+        // simply replaces y1 (whose values then bound ranks 64 .. 127 from below: still a valid BOUND).  k > 64 keeps the best
+        // 128: the chunk z first meets y1 (the better half of y1 + z survives), then y0 and y1 are merged again -- through the
+        // ONE inlined sorting network (see above).
+        const bool deep = k > 64;
+        Cand y0 = fetch(lane), y1 = fetch(64 + lane), z{-INFINITY, INT_MAX};
+        int pos = 128;
+        bool pair_yz = false;
+        for (;;) {
+            Cand a = pair_yz ? y1 : y0, b = pair_yz ? z : y1;
+            bitonic128(a, b, lane);
+            if (pair_yz) { y1 = a; pair_yz = false; continue; }
+            y0 = a; y1 = b;
+            if (pos >= n) break;
+            z = fetch(pos + lane);
             pos += 64;
-        } while (pos < n);
+            if (deep) pair_yz = true; else y1 = z;
+        }
         if (why == BOUND) {
             const int rank = k + (m_hi - m_lo) - 1;
             const float bound = rank < 64 ? __shfl(y0.v, rank & 63, 64)
@@ -522,11 +533,17 @@ __global__ __launch_bounds__(256) void select_topk_kernel(
                     out_idx[o] = lane < n ? (int64_t)y0.i : (int64_t)-1;
                     if (out_val) out_val[o] = lane < n ? y0.v : -INFINITY;
                 }
+                if (lane + 64 < k) {       // k = 65 .. 128: ranks 64 .. k - 1 sit in y1
+                    const size_t o = (size_t)q * k + lane + 64;
+                    out_idx[o] = lane + 64 < n ? (int64_t)y1.i : (int64_t)-1;
+                    if (out_val) out_val[o] = lane + 64 < n ? y1.v : -INFINITY;
+                }
                 return;
             }
             if (lane < keep) list[lane] = pack_cand(y0.v, y0.i);
+            if (lane + 64 < keep) list[lane + 64] = pack_cand(y1.v, y1.i);
             cnt = keep;
-            if (n >= k) teff = fmaxf(teff, __shfl(y0.v, k - 1, 64));   // strict from now on
+            if (n >= k) teff = fmaxf(teff, k <= 64 ? __shfl(y0.v, k - 1, 64) : __shfl(y1.v, k - 65, 64));   // strict from now on
         }
         // ---- sweep on until the list needs compacting or the row ends
         why = FINAL;
@@ -655,7 +672,7 @@ static int score_topk_impl(const float* Q, const float* C, const void* prepared,
     hipStream_t s = mmrec_stream(stream);
     if (p.materialise && !(flags & MMREC_TOPK_NO_FILTER) && topk64_filter_applicable(nq, nc, kd, k))
         return topk64_filter_launch(Q, C, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
-    if (k > MMREC_TOPK_MAX_OTHER) return MMREC_ERR_UNSUPPORTED;   // 65..128: the fp16 filter path only (kd = 64, >= 4096 candidates)
+    if (!p.materialise && k > MMREC_TOPK_MAX_OTHER) return MMREC_ERR_UNSUPPORTED;   // 65..128: not on the fused fp32 path (kd % 32 != 0)
     if (p.materialise) {
         float* Ct = nullptr;
         if (kd == 64) {

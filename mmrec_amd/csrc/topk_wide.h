@@ -233,8 +233,12 @@ __global__ __launch_bounds__(256) void wide_gather_rows_kernel(const float* __re
     for (int c = lane; c < (kd >> 2); c += 64) dst[c] = src[c];
 }
 
+// where the fp16 pass pays: the fp32 GEMM it replaces grows with nc kd per query, the exact re-scoring of 64 rows with kd only --
+// measured on kNN- and evaluation-shaped calls (profiles/r04_topk_wide_crossover.log): 7,050 x 192 / x 384 LOSE (0.51 against
+// 0.31 ms, 0.57 against 0.47), 18,357 x 192 ties, 7,050 x 1024 and everything larger wins (x 1.5 ... 3.4) -> nc kd >= 2^22
 inline bool topk_wide_applicable(int nq, int nc, int kd, int k) {
-    return kd > 128 && kd <= W_MAX_KD && kd % 32 == 0 && k <= W_MAX_K && nc >= 4096 && nq >= 1;   // (kd % 32: the rescue's fp32 GEMM)
+    return kd > 128 && kd <= W_MAX_KD && kd % 32 == 0 && k <= W_MAX_K && nc >= 4096 && nq >= 1 &&   // (kd % 32: the rescue's fp32 GEMM)
+           (size_t)nc * (size_t)kd >= ((size_t)1 << 22);
 }
 inline size_t w_al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int w_pad64(int x) { return (x + 63) / 64 * 64; }

@@ -38,7 +38,7 @@ def default_long_row_threshold(n_cols):
         return int(forced)
     return 16 if n_cols <= (1 << 18) else 32
 
-TOPK_MAX = 128            # MMREC_TOPK_MAX: kd = 64 or 128 with >= 4096 candidates; 64 for every other shape (the library says so)
+TOPK_MAX = 128            # MMREC_TOPK_MAX: every row width that is a multiple of 32; 64 for the others (the library says so)
 BPR_LOGSIG, BPR_GAMMA = 0, 1
 
 # `hip_deterministic` (config key; Trainer sets it): the backward scatters of the fused loss kernels (BPR, cosine, InfoNCE,

@@ -240,9 +240,9 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
         C = C.C
     _mat(Q, "Q"), _mat(C, "C", width=Q.shape[1])
     assert Q.shape[1] % 4 == 0, "inner dim %d is not a multiple of 4" % Q.shape[1]
-    if k > 64 and not (k <= 128 and Q.shape[1] in (64, 128) and C.shape[0] >= 4096):     # MMREC_TOPK_MAX / MMREC_TOPK_MAX_OTHER
+    if k > 128 or (k > 64 and Q.shape[1] % 32):     # MMREC_TOPK_MAX / MMREC_TOPK_MAX_OTHER
         from mmrec_amd._lib import MMRecHipError
-        raise MMRecHipError("score_topk: k = %d is served for kd = 64 with >= 4096 candidates only (<= 128)" % k)
+        raise MMRecHipError("score_topk: k = %d is served for row widths that are a multiple of 32 only (<= 128)" % k)
     if mask_rowptr is not None:
         assert mask_rowptr.dtype == torch.int32 and (mask_col is None or mask_col.dtype == torch.int32)
     s = Q @ C.t()

@@ -809,7 +809,30 @@ def test_topk_general_kd_materialised(ops, dev, kd):
     _topk_check(ops, dev, Q, C, 50, None, exact_gap=1e-4)
 
 
-@pytest.mark.parametrize("kd,nq,nc,k", [(192, 700, 5003, 10), (384, 300, 20_011, 32), (4096, 260, 4500, 10), (4096, 129, 9000, 1)])
+@pytest.mark.parametrize("kd,nc,k", [(64, 2100, 100), (64, 3000, 128), (96, 3000, 70), (256, 5000, 100), (64, 150, 128)])
+def test_topk_k_up_to_128_on_the_fp32_block_path(ops, dev, kd, nc, k):
+    """ABI 9: `select_topk_kernel` hands out up to 128 sorted entries (ranks 64 .. k - 1 from the second half of its
+    128-entry sort), so every row width that is a multiple of 32 serves k <= 128 -- candidate sets below 4096 rows at kd = 64 /
+    128 and the wide rows above k = 64 no longer send `topk: [.., 100]` runs to the dense torch path.  Masks incl. the best
+    candidates, a candidate set smaller than 2 k, duplicated candidates (ties: lower id first)."""
+    rng = np.random.default_rng(kd + nc + k)
+    nq = 77
+    Q = (rng.standard_normal((nq, kd)) / np.sqrt(kd)).astype(np.float32)
+    C = (rng.standard_normal((nc, kd)) / np.sqrt(kd)).astype(np.float32)
+    C[20:25] = C[3]
+    best = np.argsort(-(Q @ C.T), axis=1)[:, :3]
+    rows = np.concatenate([rng.integers(0, nq, 900), np.repeat(np.arange(nq), 3)])
+    cols = np.concatenate([rng.integers(0, nc, 900), best.reshape(-1)])
+    key = np.unique(rows.astype(np.int64) * nc + cols)
+    mask = np.stack([key // nc, key % nc])
+    idx = _topk_check(ops, dev, Q, C, k, mask, exact_gap=1e-4)
+    _topk_check(ops, dev, Q, C, min(k, 65), None, exact_gap=1e-4)
+    for r in range(nq):                                   # the five copies of candidate 3 appear in id order wherever they appear
+        pos = [int(np.nonzero(idx[r] == c)[0][0]) for c in (3, 20, 21, 22, 23, 24) if c in idx[r]]
+        assert pos == sorted(pos)
+
+
+@pytest.mark.parametrize("kd,nq,nc,k", [(192, 500, 22_003, 10), (384, 300, 20_011, 32), (4096, 260, 4500, 10), (4096, 129, 9000, 1)])
 def test_topk_wide_rows_fp16_pass_with_exact_refinement(ops, dev, kd, nq, nc, k):
     """kd = 192 ... 4096, >= 4096 candidates, k <= 32 (csrc/topk_wide.h: the kNN builds over raw features, freedom.py:79-91):
     fp16 matrix-core scores -> the 64 best approximate candidates per query -> margin test -> exact fp32 re-scoring, and a
@@ -1122,7 +1145,8 @@ def test_topk_filter_k_up_to_128(ops, dev, nq, nc, k):
     """k = 65..128 on the fp16 filter path (kd = 64, >= 4096 candidates; `topk: [10, 20, 50, 100]` evaluates fused instead
     of through rocBLAS + torch.topk): rows of bits and word lists, the final kernel's two-register rank order, the slow queue
     (a heavy user whose k + #masked exceeds the group maxima; a query whose candidates all tie; >= 65,536 candidates: split
-    over workgroups and merged) -- against orc.mask_topk (trainer.py:304-309); smaller candidate sets say UNSUPPORTED."""
+    over workgroups and merged) -- against orc.mask_topk (trainer.py:304-309); smaller candidate sets take the fp32 block path,
+    row widths that are not a multiple of 32 say UNSUPPORTED."""
     from mmrec_amd._lib import MMRecHipError
     rng = np.random.default_rng(nq + nc + k)
     Q = rng.standard_normal((nq, 64)).astype(np.float32) * 0.2
@@ -1140,8 +1164,9 @@ def test_topk_filter_k_up_to_128(ops, dev, nq, nc, k):
     rp, col = ops.mask_to_csr(mask, nq, dev)
     a = ops.score_topk(D(Q, dev), D(C, dev), k, rp, col, return_values=True)
     assert np.array_equal(a[0].cpu().numpy(), idx)                       # repeatable
+    _topk_check(ops, dev, Q, C[:3000].copy(), k)                         # below 4096 candidates: the fp32 block path (k <= 128 since ABI 9)
     with pytest.raises(MMRecHipError):
-        ops.score_topk(D(Q, dev), D(C[:3000], dev), k)                   # below 4096 candidates: 64 is the limit
+        ops.score_topk(D(Q[:, :40].copy(), dev), D(C[:3000, :40].copy(), dev), k)     # kd % 32 != 0: the fused fp32 path stops at 64
 
 
 @pytest.mark.parametrize("nq,nc,k", [(600, 7050, 50), (300, 40_037, 50), (64, 70_001, 100), (517, 4096, 20)])

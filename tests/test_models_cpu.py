@@ -169,8 +169,8 @@ def test_reference_model_files_run_on_our_plumbing(tmp_path_factory, golden, run
 def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     """Round-1 advice: (1) a model on the reference's dense evaluation path (no `full_sort_topk`, or k above the fused
     kernel's limit) must not be handed the fused path's 65,536-user batches as ONE [batch, n_items] score block: the
-    Trainer walks such a batch in `eval_batch_size` slices, with the same per-user results; (2) `topk: [5, 70]` (k > 64,
-    fine for torch.topk in the reference) evaluates through the dense path instead of raising after a training epoch."""
+    Trainer walks such a batch in `eval_batch_size` slices, with the same per-user results; (2) `topk: [5, 70]` (k > 64) is served
+    by the kernels, and a shape they refuse evaluates through the dense path instead of raising after a training epoch."""
     from mmrec_amd.common.trainer import Trainer
     config, train_data, valid_data, model = G.build(tmp_path, golden, "LightGCN", {"n_layers": 2, "reg_weight": 1e-4})
     trainer = Trainer(config, model)
@@ -183,25 +183,38 @@ def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     trainer.test_batch_size = 37
     sliced = trainer.evaluate(valid_data)
     assert sliced == whole == fused and max(sizes) <= 37 and len(sizes) > 1
+    from mmrec_amd._lib import MMRecHipError
     config["topk"] = [5, 70]
-    t2 = Trainer(config, model)                    # fused evaluation on, but k = 70 > 64 on a 90-item dataset (128 needs >= 4096 items)
+    t2 = Trainer(config, model)                    # k = 70 > 64: served by the kernels since ABI 9 (every row width that is a multiple of 32)
     sizes.clear()
     res = t2.evaluate(valid_data)
-    assert sizes and res["recall@5"] == whole["recall@5"] and "recall@70" in res
+    assert not sizes and t2.eval_path.startswith("fused") and res["recall@5"] == whole["recall@5"] and "recall@70" in res
+    # a shape the kernel refuses (here: forced) evaluates through the dense path instead of raising after a training epoch
+    real_topk = model.full_sort_topk
+
+    def refusing(batch, k):
+        raise MMRecHipError("score_topk: forced refusal")
+    model.full_sort_topk = refusing
+    t2b = Trainer(config, model)
+    res_b = t2b.evaluate(valid_data)
+    assert sizes and res_b == res
     # round-3 review (weak 8): the path that ranked an evaluation is RECORDED, and `strict_fused_eval` refuses the fallback
     assert trainer.eval_path.startswith("dense") and "hip_fused_eval: False" in trainer.eval_path
-    assert t2.eval_path.startswith("dense") and "refused the shape" in t2.eval_path and sum(t2.eval_paths.values()) == 1
+    assert t2b.eval_path.startswith("dense") and "refused the shape" in t2b.eval_path and sum(t2b.eval_paths.values()) == 1
+    model.full_sort_topk = real_topk
     config["topk"] = [5, 20]
     t3 = Trainer(config, model)
     t3.evaluate(valid_data)
     assert t3.eval_path.startswith("fused")
-    from mmrec_amd._lib import MMRecHipError
-    config["topk"], config["strict_fused_eval"] = [5, 70], True
-    with pytest.raises(MMRecHipError):             # k = 70 on 90 items: the kernel says no, and strict mode lets it
-        Trainer(config, model).evaluate(valid_data)
+    config["strict_fused_eval"] = True             # (the raising evaluations come last: they leave the loader mid-iteration)
     config["topk"] = [5, 200]
     with pytest.raises(RuntimeError, match="strict_fused_eval"):
         Trainer(config, model).evaluate(valid_data)
+    config["topk"] = [5, 70]
+    model.full_sort_topk = refusing
+    with pytest.raises(MMRecHipError):             # the kernel says no, and strict mode lets it
+        Trainer(config, model).evaluate(valid_data)
+    model.full_sort_topk = real_topk
 
 
 def test_adjacent_id_tables_layout(tmp_path, golden):

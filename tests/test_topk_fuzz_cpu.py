@@ -25,7 +25,9 @@ def test_generator_covers_every_plan_switch_and_is_deterministic():
     assert (ncs < 200).any() and (ncs > 200_000).any()
     assert {c["kd"] for c in metas} == {64, 128, 192, 384} and max(c["k"] for c in metas) == 128 and min(c["k"] for c in metas) == 1
     wide = [c for c in metas if c["kd"] > 128 and c["nc"] >= 4096]
-    assert any(c["k"] <= 32 for c in wide) and any(c["k"] > 32 for c in wide) and all(c["k"] <= 64 for c in wide)
+    # wide rows: the fp16 pass (k <= 32), the fp32 block path above (incl. its k > 64 form) -- all occur
+    assert any(c["k"] <= 32 for c in wide) and any(32 < c["k"] <= 64 for c in wide) and any(c["k"] > 64 for c in wide)
+    assert any(c["k"] > 64 and c["nc"] < 4096 and c["kd"] <= 128 for c in metas)        # select_topk_kernel's second half
     tags = {t for c in cases for t in c["tags"]}
     assert {"qspread", "cspread", "outliers", "ties", "heavy", "bestmasked", "zeroq", "starved", "dupq"} <= tags, tags
     a, b = F.gen_case(7, scale=0.02, work=3.0e5), F.gen_case(7, scale=0.02, work=3.0e5)

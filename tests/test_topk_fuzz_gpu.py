@@ -6,9 +6,9 @@ neither of its two real bugs (subnormal query rows, overflowing lists) except by
 cases over
 
     nq in [1, 3000], nc in [1, 300,000] (with extra weight on both sides of every plan switch: 4096 / 32,768 / 65,536 /
-    131,072 candidates), k in [1, 128] (<= 64 below 4096 candidates and for the wide rows: the materialised path's limit), kd in
+    131,072 candidates), k in [1, 128], kd in
     {64, 128} and, in a quarter of the cases, {192, 384} (the fp16 pass + exact refinement of csrc/topk_wide.h for k <= 32,
-    the fp32 path above),
+    the fp32 block path above),
     mask density (none / sparse / the train-positive shape / heavy users with 600 and 5,000 masked items, optionally the
     query's BEST candidates masked), per-row norm spread up to 2^+-40 on the queries and 2^+-12 on the candidates, a common
     component (what LightGCN smoothing produces), outlying candidate rows (x 5..25: trained item tables), all-zero query
@@ -59,7 +59,7 @@ def gen_case(seed, scale=None, work=None, meta_only=False):
     if rng.random() < 0.15:
         nq = int(rng.choice([1, 31, 32, 33, 255, 256, 257, 511, 513]))
     nq = max(1, min(nq, int(work // nc)))
-    kmax = min(nc, 128 if (nc >= 4096 and kd <= 128) else 64)
+    kmax = min(nc, 128)          # every kd here is a multiple of 32: k <= 128 on all paths since ABI 9
     k = int(rng.choice([1, 5, 10, 20, 50, 64, 65, 100, 128])) if rng.random() < 0.6 else int(rng.integers(1, 129))
     k = max(1, min(k, kmax))
     if meta_only:
