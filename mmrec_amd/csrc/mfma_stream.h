@@ -207,16 +207,13 @@ __global__ __launch_bounds__(320, 2) void gemm64_stream_kernel(const float* __re
 // swizzle as in gemm.hip's forward), one barrier per tile, tile t+1 in flight under the 64 MFMAs per
 // wave of tile t.  32 FLOP per operand byte; consecutive workgroups share the C tile through L2 and
 // the query block is small enough to stay cache resident, so HBM streams C once per query block.
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A,
-                                                        const float* __restrict__ B,
-                                                        const float* __restrict__ bias,
-                                                        float* __restrict__ S, int M, int N, int K,
-                                                        int lds_, int ncols, const int* __restrict__ m_live) {
-    __shared__ __attribute__((aligned(1024))) float As0[128 * 32], As1[128 * 32], Bs0[128 * 32], Bs1[128 * 32];
+// one 128 x 128 output tile at (m0, n0); As0 .. Bs1: the workgroup's four 16 KB LDS stages
+__device__ __forceinline__ void gemm_nt_tile(const float* __restrict__ A, const float* __restrict__ B,
+                                             const float* __restrict__ bias, float* __restrict__ S, int M, int N, int K,
+                                             int lds_, int ncols, int m0, int n0, float* As0, float* As1, float* Bs0,
+                                             float* Bs1) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    if (m_live && m0 >= *m_live) return;   // a device-side row count (topk_wide.h: the re-scored queries): nothing to do here
     const int rows_a = min(128, M - m0), rows_b = max(0, min(128, N - n0));
     const i32x4 ra = raw_rsrc(A + (size_t)m0 * K, (unsigned)rows_a * (unsigned)K * 4u);
     const i32x4 rb = raw_rsrc(B + (size_t)n0 * K, (unsigned)rows_b * (unsigned)K * 4u);
@@ -289,11 +286,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A,
+                                                        const float* __restrict__ B,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ S, int M, int N, int K,
+                                                        int lds_, int ncols) {
+    __shared__ __attribute__((aligned(1024))) float As0[128 * 32], As1[128 * 32], Bs0[128 * 32], Bs1[128 * 32];
+    gemm_nt_tile(A, B, bias, S, M, N, K, lds_, ncols, blockIdx.x * 128, blockIdx.y * 128, As0, As1, Bs0, Bs1);
+}
+
+// The same GEMM over the first *m_live rows of A only -- a DEVICE-side row count (topk_wide.h: the queries on the rescue
+// queue, usually none).  A 1-D grid of resident workgroups walks the live tiles (row tile fastest: the workgroups of a
+// round share one 128-row slab of B through L2); with an empty queue every workgroup returns at once.  (The 2-D grid of the
+// plain kernel dispatched 125,000 workgroups with 64 KB of LDS each just to have them return: 0.93 ms per 4096 x 500,000
+// block, 0.22 s of the config-5 kNN builds -- profiles/r04_c5_plugin_kernels.txt.)
+__global__ __launch_bounds__(256, 2) void gemm_nt_live_kernel(const float* __restrict__ A,
+                                                             const float* __restrict__ B,
+                                                             float* __restrict__ S, int M, int N, int K,
+                                                             int lds_, int ncols, const int* __restrict__ m_live) {
+    __shared__ __attribute__((aligned(1024))) float As0[128 * 32], As1[128 * 32], Bs0[128 * 32], Bs1[128 * 32];
+    const int live = min(*m_live, M);
+    if (live <= 0) return;
+    const int tm = (live + 127) / 128, total = tm * ((ncols + 127) / 128);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        gemm_nt_tile(A, B, nullptr, S, M, N, K, lds_, ncols, (t % tm) * 128, (t / tm) * 128, As0, As1, Bs0, Bs1);
+        __syncthreads();       // the next tile's first LDS-DMA must not land while a wave still reads this tile's last stage
+    }
+}
+
 // `ncols` columns of every row are written (>= N: the columns past N hold zeros + nothing else).
 inline void gemm_nt_launch(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
                            int ldc, int ncols, hipStream_t s, const int* m_live = nullptr) {
+    if (m_live) {
+        const long tiles = (long)((M + 127) / 128) * ((ncols + 127) / 128);
+        hipLaunchKernelGGL(gemm_nt_live_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, s, A, B, C, M, N, K,
+                           ldc, ncols, m_live);
+        return;
+    }
     hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + 127) / 128, (ncols + 127) / 128), dim3(256), 0, s, A, B, bias, C,
-                       M, N, K, ldc, ncols, m_live);
+                       M, N, K, ldc, ncols);
 }
 
 // Launch of gemm64_stream_kernel.  f tiles per workgroup: long walks win (measured: 8 tiles beat 2 even
