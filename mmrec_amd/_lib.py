@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MMREC_HIP_LIB: load another build of the same library (kernel A/B measurements: tools/prof_topk_filter.py)
 LIB_PATH = os.environ.get("MMREC_HIP_LIB") or os.path.join(_PKG, "lib", "libmmrec_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _P = c_void_p  # every device/host pointer travels as void*
 
@@ -35,6 +35,8 @@ SIGNATURES = {
     "mmrec_bpr_workspace_bytes": (c_size_t, [c_int32]),
     "mmrec_bpr_fwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, _P,
                                     _P, _P, _P]),
+    "mmrec_spmm_rows_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "mmrec_spmm_push_rows_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "mmrec_bpr_dots_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P]),
     "mmrec_bpr_loss_from_dots_f32": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P, _P, _P]),
     "mmrec_bpr_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, c_float, _P, _P,

@@ -7,3 +7,9 @@ int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float
                        const float* Z, const float* acc_in, float* acc_out, int n_rows, int d, float alpha, float beta,
                        float acc_scale, int long_t, const int32_t* long_rows, const int32_t* long_chunk_ptr, int n_long,
                        int n_chunks, float* partials, hipStream_t s);
+
+// listed rows only (pull, in the full launch's order) and its transpose-free atomic backward (push); d = 8 / 16 / 32 / 64
+int spmm_pull_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, const float* Z,
+                          const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s);
+int spmm_push_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G,
+                          const int64_t* rows, int n_list, int d, float* dX, float* dZ, hipStream_t s);

@@ -80,6 +80,7 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
         self.lazy_feature_adam = lazy_adam_enabled(config, n_feat) and self.lazy_projection
         self.lazy_prefetch = config['lazy_prefetch'] is not False    # new key: catch-up on a side stream (default on)
+        self.pull_batch_rows = config['hip_pull_batch_rows'] is not False   # new key: item-item layer at the batch rows only
         self.n_nodes = self.n_users + self.n_items
 
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
@@ -145,7 +146,15 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
                 for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
                     if emb is not None:
                         emb.prefetch(rows)
-        ua, ia = self.forward(self.masked_adj)
+        pull = self.lazy_projection and self.pull_batch_rows and self.n_layers == 1
+        if pull:
+            # The item-item layer (freedom.py:173-177) is consumed at the batch's pos / neg rows only (:198-199): those 2B rows
+            # of `mm_adj @ item_emb + i_g` are pulled (same bits as the full launch) and their gradient is pushed through the
+            # listed rows -- 4096 of 500,000 rows at config 5, two full item-item launches per step gone.
+            ua, ia = hip_ops.lightgcn_mean_parts(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
+                                                 self.n_ui_layers)
+        else:
+            ua, ia = self.forward(self.masked_adj)
         self.build_item_graph = False
         if self.lazy_projection:
             # The reference projects ALL items every batch (freedom.py:205,208) but only the pos/neg rows
@@ -162,7 +171,9 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
                 terms.append((hip_ops.linear(gather(self.text_embedding), self.text_trs.weight, self.text_trs.bias), lp, ln))
             if self.v_feat is not None:
                 terms.append((hip_ops.linear(gather(self.image_embedding), self.image_trs.weight, self.image_trs.bias), lp, ln))
-            return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, joint_grad=True), self.t_feat is not None, self.reg_weight)
+            return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, joint_grad=True,
+                                                            pull=(self.mm_adj, self.item_id_embedding.weight) if pull else None),
+                            self.t_feat is not None, self.reg_weight)
         loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
         mf_t = mf_v = 0.0
         if self.t_feat is not None:
@@ -520,6 +531,7 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         # are capturable; common/graph_step.py falls back to eager launches if a capture fails).  Off by default: it could only
         # be exercised on a one-rank group so far.
         self.graph_capturable = bool(config['dist_graph_step'])
+        self.pull_batch_rows = config['hip_pull_batch_rows'] is not False
         nu, ni = self.n_users, self.n_items
         self.n_nodes = nu + ni
 
@@ -618,7 +630,12 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
 
     def calculate_loss(self, interaction):
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
-        ua, ia = self.forward(self.masked_adj)
+        pull = self.pull_batch_rows and self.n_layers == 1      # the item-item layer at the batch rows only (see FREEDOM)
+        if pull:
+            ua, ia = hip_ops.lightgcn_mean_parts(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
+                                                 self.n_ui_layers)
+        else:
+            ua, ia = self.forward(self.masked_adj)
         rows = torch.cat((pos_items, neg_items))
         b = pos_items.shape[0]
         lp = torch.arange(b, device=rows.device)
@@ -628,7 +645,8 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
             terms.append((self._owned_projection(self.text_embedding, self.text_trs, rows), lp, ln))
         if self.has_image:
             terms.append((self._owned_projection(self.image_embedding, self.image_trs, rows), lp, ln))
-        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, sum_over_ranks=self._sum_over_ranks),
+        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, sum_over_ranks=self._sum_over_ranks,
+                                                        pull=(self.mm_adj, self.item_id_embedding.weight) if pull else None),
                         self.has_text, self.reg_weight)
 
     def _sum_over_ranks(self, t):

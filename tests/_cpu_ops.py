@@ -177,7 +177,10 @@ class _SumOverRanks(torch.autograd.Function):
         return g, None
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None):
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None,
+                            pull=None):
+    if pull is not None:                 # the first term's table is graph @ X + Z, consumed at the term's rows
+        terms = [(spmm(pull[0], pull[1], Z=terms[0][0]),) + tuple(terms[0][1:])] + list(terms[1:])
     if sum_over_ranks is None:
         return tuple(bpr_loss(U, I, users, pos, neg, variant, reduction) for I, pos, neg in terms)
     assert U.shape[1] % EMB_DIM == 0 or U.shape[1] in SLICE_WIDTHS, "slice width the kernels have"

@@ -403,6 +403,91 @@ def test_bpr_variants_with_duplicates(ops, dev, variant, reduction):
     close(Id.grad, I.grad, atol=1e-6)
 
 
+def _rows_test_graph(ops, dev, kind, rng):
+    if kind == "knn":                     # 20 nonzeros in every row (two 10-NN graphs summed, uncoalesced): above the 16-nonzero
+        n = 5000                          # threshold of a cache-resident graph -> every row is a single-chunk "long" row
+        rows = np.repeat(np.arange(n), 20)
+        cols = rng.integers(0, n, rows.shape[0])
+    else:                                 # empty rows, short rows, single-chunk long rows (<= 512 nonzeros)
+        n = 6000
+        degs = np.minimum(rng.zipf(1.6, n), 500)
+        degs[::7] = 0
+        rows = np.repeat(np.arange(n), degs)
+        cols = rng.integers(0, n, rows.shape[0])
+    vals = rng.standard_normal(rows.shape[0]).astype(np.float32)
+    return ops.CsrGraph.from_coo_host(np.stack([rows, cols]), vals, n, n, dev, long_row_threshold=None), n
+
+
+@pytest.mark.parametrize("kind", ["knn", "mixed"])
+@pytest.mark.parametrize("d", [8, 16, 32, 64])
+def test_spmm_listed_rows_pull_is_bitwise_the_full_launch_and_push_is_its_transpose(ops, dev, d, kind):
+    """mmrec_spmm_rows_f32 / mmrec_spmm_push_rows_f32 (ABI 10; FREEDOM's item-item layer read at the batch rows only,
+    freedom.py:173-177, 197-199): the pulled rows carry the bits of the full launch -- short rows (one chain) and single-chunk
+    long rows (the chunk block's 16-group order), with and without the residual Z, duplicated and unordered row lists -- and the
+    push is the transposed product of the listed rows (fp32 atomics: compared with float64 to rounding)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(d + len(kind))
+    g, n = _rows_test_graph(ops, dev, kind, rng)
+    assert ops.rows_servable(g, d) and (kind != "knn" or g.n_long == n)
+    X = D(rng.standard_normal((n, d)).astype(np.float32), dev)
+    Z = D(rng.standard_normal((n, d)).astype(np.float32), dev)
+    rows = torch.from_numpy(np.concatenate([rng.integers(0, n, 3000), [0, n - 1, 5, 5, 5]])).to(dev)
+    for z in (None, Z):
+        full = torch.empty(n, d, device=dev)
+        ops.spmm_raw(g, X, Y=full, Z=z)
+        got = ops.spmm_rows_raw(g, X, rows, Z=z)
+        assert torch.equal(got, full[rows])
+    G = D(rng.standard_normal((rows.numel(), d)).astype(np.float32), dev)
+    dX, dZ = torch.zeros(n, d, device=dev), torch.zeros(n, d, device=dev)
+    ops.spmm_push_rows_raw(g, G, rows, dX, dZ)
+    idx, val = g.to_coo_host()
+    A = sp.csr_matrix((val.astype(np.float64), (idx[0], idx[1])), shape=(n, n))
+    r = rows.cpu().numpy()
+    ref_x = A[r].T @ G.cpu().numpy().astype(np.float64)
+    ref_z = np.zeros((n, d))
+    np.add.at(ref_z, r, G.cpu().numpy().astype(np.float64))
+    close(dX, ref_x, rtol=1e-5, atol=1e-5)
+    close(dZ, ref_z, rtol=1e-6, atol=1e-6)
+    # a graph with a row spanning several chunks is not served: the caller keeps the full launch
+    big = ops.CsrGraph.from_coo_host(np.stack([np.zeros(2000, np.int64), rng.integers(0, 3000, 2000)]),
+                                     np.ones(2000, np.float32), 3000, 3000, dev, long_row_threshold=None)
+    assert not ops.rows_servable(big, d)
+    with pytest.raises(Exception):
+        ops.spmm_rows_raw(big, X[:3000].contiguous(), rows[:10] % 3000)
+
+
+@pytest.mark.parametrize("d", [64, 16])
+def test_shared_user_bpr_with_pulled_item_rows_equals_the_full_item_item_launch(ops, dev, d):
+    """hip_ops.bpr_losses_shared_users(..., pull=(graph, X)): the first term's table graph @ X + Z is read at its pos / neg rows
+    only -- the losses are those of the full launch BIT FOR BIT (forward), the gradients of U, Z and X agree with the full
+    launch's autograd to rounding (push by atomics against pull sums); joint gradient buffer and a sliced width included."""
+    rng = np.random.default_rng(d)
+    g, n = _rows_test_graph(ops, dev, "knn", rng)
+    g.transpose()
+    nu, B = 700, 333
+    U0, X0, Z0 = (rng.standard_normal((m, d)).astype(np.float32) * 0.3 for m in (nu, n, n))
+    T0 = rng.standard_normal((2 * B, d)).astype(np.float32) * 0.3
+    users = torch.from_numpy(rng.integers(0, nu // 2, B)).to(dev)
+    pos, neg = (torch.from_numpy(rng.integers(0, n // 4, B)).to(dev) for _ in range(2))      # duplicates on purpose
+    lp = torch.arange(B, device=dev)
+    ln = lp + B
+    kw = dict(sum_over_ranks=(lambda t: None)) if d != 64 else dict(joint_grad=True)
+
+    def run(pulled):
+        u, x, z, t = (D(a, dev, True) for a in (U0, X0, Z0, T0))
+        if pulled:
+            ls = ops.bpr_losses_shared_users(u, users, [(z, pos, neg), (t, lp, ln)], pull=(g, x), **kw)
+        else:
+            ls = ops.bpr_losses_shared_users(u, users, [(ops.spmm(g, x, Z=z), pos, neg), (t, lp, ln)], **kw)
+        (ls[0] + 0.37 * ls[1]).backward()
+        return [v.detach().cpu() for v in ls], [v.grad.cpu() for v in (u, x, z, t)]
+
+    (la, ga), (lb, gb) = run(True), run(False)
+    assert all(torch.equal(a, b) for a, b in zip(la, lb))
+    for a, b in zip(ga, gb):
+        close(a, b, rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_sliced_shared_user_bpr_equals_the_full_width_op(ops, dev, world, variant):
@@ -1442,6 +1527,38 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
             np.testing.assert_allclose(res[True][2][name].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=atol, err_msg=name)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph_step", [False, True])
+def test_freedom_plugin_pulled_item_rows_equals_full_item_item_layer(tmp_path, golden, dev, graph_step):
+    """config `hip_pull_batch_rows` (default on): FREEDOM's training step computes the item-item layer at the batch rows only.
+    One epoch through the Trainer (eager and replayed as a hipGraph) + an evaluation against the same run with the key off:
+    the first step's loss bit for bit (same forward bits), the epoch's loss, parameters and metrics to rounding (the backward's
+    push uses fp32 atomics)."""
+    from mmrec_amd.common.trainer import Trainer
+    from mmrec_amd.utils.utils import get_model
+    from tests._env import setup
+    res = {}
+    for pull in (True, False):
+        extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "hip_pull_batch_rows": pull,
+                 "hip_graph_step": graph_step}
+        config, train_data, valid_data = setup(tmp_path / ("p%d" % pull), golden, "FREEDOM", extra, use_gpu=True)
+        model = get_model("FREEDOM")(config, train_data).to(config["device"])
+        assert model.pull_batch_rows == pull
+        gen = torch.Generator().manual_seed(3)
+        keep = torch.multinomial(model.edge_values.detach().cpu(), int(model.edge_values.numel() * 0.2), generator=gen)
+        model.set_kept_edges(keep.to(dev))
+        first = float(model.calculate_loss(next(iter(train_data))))
+        trainer = Trainer(config, model)
+        loss, _ = trainer._train_epoch(train_data, 0)
+        metrics = trainer.evaluate(valid_data)
+        res[pull] = (first, float(loss), metrics, {n: p.detach().clone() for n, p in model.named_parameters()})
+    assert res[True][0] == res[False][0]
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=1e-6)
+    assert res[True][2] == res[False][2]
+    for name, ref in res[False][3].items():
+        atol = 1e-4 if name.endswith("trs.bias") else 2e-6       # analytically-zero gradient: Adam-normalised noise
+        np.testing.assert_allclose(res[True][3][name].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=atol, err_msg=name)
 
 
 @pytest.mark.parametrize("multi", [True, False])
