@@ -85,19 +85,21 @@ int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float
                        const int32_t* long_chunk_ptr, int32_t n_long, int32_t n_chunks,
                        float* partials, int32_t* long_tickets, mmrec_stream_t stream);
 
-/* The same product at LISTED rows only (ABI 10): Y[i] = (A X)[rows[i]] (+ Z[rows[i]]), i < n_list, rows int64 (duplicates
- * allowed), Y [n_list, d] compact, d = 8 / 16 / 32 / 64.  For the training step of a model that consumes a propagated table at
- * its batch rows only -- FREEDOM's item-item layer, freedom.py:173-177 read at :197-199: 4096 of 500,000 rows at config 5.
+/* The same product at LISTED rows only (ABI 10): Y[i] = (A X)[rows[i]] + Z[rows[i]] (z_compact = 0; Z may be NULL) or
+ * + Z[i] (z_compact = 1: Z is [n_list, d] like Y), i < n_list, rows int64 (duplicates allowed), Y [n_list, d] compact,
+ * d = 8 / 16 / 32 / 64.  For the training step of a model that consumes a propagated table at its batch rows only -- FREEDOM's
+ * item-item layer, freedom.py:173-177 read at :197-199: 4096 of 500,000 rows at config 5.
  * Bits: those of mmrec_spmm_csr_f32 with the same long_row_threshold for every row that does not span several chunks
  * (n_chunks == n_long in the graph's plan; callers keep the full launch otherwise).
- * mmrec_spmm_push_rows_f32 is its backward without a transposed graph: dX[c] += A[r, c] G[i] over the nonzeros (r, c) of the
- * listed rows r = rows[i], and dZ[r] += G[i] (either may be NULL); fp32 atomics into caller-zeroed / accumulating buffers, so
- * the order of the sums differs from the full launch's in the last ulp (as the sampled-scoring backward's scatters do). */
+ * mmrec_spmm_push_rows_f32 is the transposed product of the listed rows without a transposed graph:
+ * dX[c] += A[r, c] * g_scale * G[i] over the nonzeros (r, c) of the listed rows r = rows[i], and dZ[r] += g_scale * G[i]
+ * (either may be NULL; dZ may alias dX); one workgroup per listed row; fp32 atomics into caller-zeroed / accumulating buffers,
+ * so the order of the sums differs from a pull launch's in the last ulp (as the sampled-scoring backward's scatters do). */
 int mmrec_spmm_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
-                        const float* Z, const int64_t* rows, int32_t n_list, int32_t d,
+                        const float* Z, int32_t z_compact, const int64_t* rows, int32_t n_list, int32_t d,
                         int32_t long_row_threshold, float* Y, mmrec_stream_t stream);
 int mmrec_spmm_push_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G,
-                             const int64_t* rows, int32_t n_list, int32_t d, float* dX, float* dZ,
+                             float g_scale, const int64_t* rows, int32_t n_list, int32_t d, float* dX, float* dZ,
                              mmrec_stream_t stream);
 
 /* One LayerGCN layer in one launch (layergcn.py:131-135): y = A x ; w[row] = cosine_similarity(y[row], ego[row]) with

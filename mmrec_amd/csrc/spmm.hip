@@ -495,23 +495,23 @@ extern "C" int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, 
 // (layergcn.py:131-135; SURVEY.md 8b `spmm_csr_f32_layergcn`).  The cosine needs the finished row, which the group that
 // stores it holds in registers in all three places a row is finished (row blocks, single-chunk blocks, long-row reduce).
 extern "C" int mmrec_spmm_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
-                                   const float* Z, const int64_t* rows, int32_t n_list, int32_t d,
+                                   const float* Z, int32_t z_compact, const int64_t* rows, int32_t n_list, int32_t d,
                                    int32_t long_row_threshold, float* Y, mmrec_stream_t stream) {
     if (d != 8 && d != 16 && d != 32 && d != 64) return MMREC_ERR_UNSUPPORTED;
     if (n_list < 0 || long_row_threshold < 0) return MMREC_ERR_BAD_ARG;
     if (n_list == 0) return 0;
     if (!rowptr || !X || !rows || !Y || Y == X) return MMREC_ERR_BAD_ARG;
-    return spmm_pull_rows_launch(rowptr, colidx, vals, X, Z, rows, n_list, d, long_row_threshold, Y, mmrec_stream(stream));
+    return spmm_pull_rows_launch(rowptr, colidx, vals, X, Z, z_compact, rows, n_list, d, long_row_threshold, Y, mmrec_stream(stream));
 }
 
 extern "C" int mmrec_spmm_push_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G,
-                                        const int64_t* rows, int32_t n_list, int32_t d, float* dX, float* dZ,
+                                        float g_scale, const int64_t* rows, int32_t n_list, int32_t d, float* dX, float* dZ,
                                         mmrec_stream_t stream) {
     if (d != 8 && d != 16 && d != 32 && d != 64) return MMREC_ERR_UNSUPPORTED;
     if (n_list < 0) return MMREC_ERR_BAD_ARG;
     if (n_list == 0) return 0;
     if (!rowptr || !G || !rows || (!dX && !dZ)) return MMREC_ERR_BAD_ARG;
-    return spmm_push_rows_launch(rowptr, colidx, vals, G, rows, n_list, d, dX, dZ, mmrec_stream(stream));
+    return spmm_push_rows_launch(rowptr, colidx, vals, G, g_scale, rows, n_list, d, dX, dZ, mmrec_stream(stream));
 }
 
 extern "C" int mmrec_spmm_csr_f32_layergcn(const int32_t* rowptr, const int32_t* colidx, const float* vals,

@@ -165,15 +165,15 @@ __global__ __launch_bounds__(256) void spmm_narrow_long_reduce_kernel(
 
 // ---- listed rows only (the training step of a model that consumes a propagated table at its BATCH rows: FREEDOM's item-item
 // layer, freedom.py:173-177 + 197-199 -- 4096 of 500,000 rows at config 5) ---------------------------------------------------
-// Y[i] = (A X)[rows[i]] (+ Z[rows[i]]), one LPR-lane sub-group per listed row, in the order of the full launch: a row of at
+// Y[i] = (A X)[rows[i]] (+ Z[rows[i]], or + Z[i] for a compact Z), one LPR-lane sub-group per listed row, in the order of the full launch: a row of at
 // most long_t nonzeros is one sequential chain (gather_span); a longer row that fits ONE chunk is summed as its chunk block
 // does -- 16 virtual groups over spans of 16 nonzeros at stride 256, then the fixed-order sum over the groups -- so the listed
 // rows carry the full launch's bits (rows spanning several chunks are not served: the caller keeps the full launch).
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_pull_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-    const float* __restrict__ X, const float* __restrict__ Z, const int64_t* __restrict__ rows, int n_list, int long_t,
-    float* __restrict__ Y) {
+    const float* __restrict__ X, const float* __restrict__ Z, int z_compact, const int64_t* __restrict__ rows, int n_list,
+    int long_t, float* __restrict__ Y) {
     const int t = threadIdx.x % LPR;
     const int i = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (i >= n_list) return;                                   // uniform within the sub-group
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void spmm_pull_rows_kernel(
         }
     }
     float4 y = f4_scale(1.f, sum);
-    if (Z) y = f4_fma(1.f, reinterpret_cast<const float4*>(Z)[(size_t)row * LPR + t], y);
+    if (Z) y = f4_fma(1.f, reinterpret_cast<const float4*>(Z)[(size_t)(z_compact ? i : row) * LPR + t], y);
     reinterpret_cast<float4*>(Y)[(size_t)i * LPR + t] = y;
 }
 
@@ -202,23 +202,25 @@ __global__ __launch_bounds__(256) void spmm_pull_rows_kernel(
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_push_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-    const float* __restrict__ G, const int64_t* __restrict__ rows, int n_list, float* __restrict__ dX,
+    const float* __restrict__ G, float g_scale, const int64_t* __restrict__ rows, int n_list, float* __restrict__ dX,
     float* __restrict__ dZ) {
-    const int t = threadIdx.x % LPR;
-    const int i = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-    if (i >= n_list) return;
+    // one WORKGROUP per listed row, its 256 / LPR sub-groups striding over the row's nonzeros: a batch holds popular items
+    // whose rows have thousands of nonzeros (one sub-group alone would take a millisecond on such a row)
+    constexpr int SG = 256 / LPR;
+    const int t = threadIdx.x % LPR, sg = threadIdx.x / LPR;
+    const int i = blockIdx.x;
     const int row = (int)rows[i];
-    const float4 g = reinterpret_cast<const float4*>(G)[(size_t)i * LPR + t];
+    const float4 g = f4_scale(g_scale, reinterpret_cast<const float4*>(G)[(size_t)i * LPR + t]);
     auto add4 = [&](float* base, float4 v) {
         unsafeAtomicAdd(base + 0, v.x);
         unsafeAtomicAdd(base + 1, v.y);
         unsafeAtomicAdd(base + 2, v.z);
         unsafeAtomicAdd(base + 3, v.w);
     };
-    if (dZ) add4(dZ + ((size_t)row * LPR + t) * 4, g);
+    if (dZ && sg == 0) add4(dZ + ((size_t)row * LPR + t) * 4, g);
     if (!dX) return;
     const int s = rowptr[row], e = rowptr[row + 1];
-    for (int k = s; k < e; ++k) add4(dX + ((size_t)colidx[k] * LPR + t) * 4, f4_scale(vals[k], g));
+    for (int k = s + sg; k < e; k += SG) add4(dX + ((size_t)colidx[k] * LPR + t) * 4, f4_scale(vals[k], g));
 }
 
 template <int LPR>
@@ -261,10 +263,10 @@ int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float
 }
 
 int spmm_pull_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, const float* Z,
-                          const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s) {
+                          int z_compact, const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s) {
 #define MMREC_PULL(L)                                                                                                     \
     hipLaunchKernelGGL(spmm_pull_rows_kernel<L>, dim3((n_list + 256 / L - 1) / (256 / L)), dim3(256), 0, s, rowptr, colidx, vals, \
-                       X, Z, rows, n_list, long_t, Y)
+                       X, Z, z_compact, rows, n_list, long_t, Y)
     switch (d) {
         case 8: MMREC_PULL(2); break;
         case 16: MMREC_PULL(4); break;
@@ -276,11 +278,11 @@ int spmm_pull_rows_launch(const int32_t* rowptr, const int32_t* colidx, const fl
     return (int)hipGetLastError();
 }
 
-int spmm_push_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G,
+int spmm_push_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G, float g_scale,
                           const int64_t* rows, int n_list, int d, float* dX, float* dZ, hipStream_t s) {
 #define MMREC_PUSH(L)                                                                                                     \
-    hipLaunchKernelGGL(spmm_push_rows_kernel<L>, dim3((n_list + 256 / L - 1) / (256 / L)), dim3(256), 0, s, rowptr, colidx, vals, \
-                       G, rows, n_list, dX, dZ)
+    hipLaunchKernelGGL(spmm_push_rows_kernel<L>, dim3(n_list), dim3(256), 0, s, rowptr, colidx, vals, G, g_scale, rows, n_list, \
+                       dX, dZ)
     switch (d) {
         case 8: MMREC_PUSH(2); break;
         case 16: MMREC_PUSH(4); break;

@@ -335,34 +335,69 @@ def rows_servable(g: CsrGraph, d):
     return g.n_chunks == g.n_long and d in SLICE_WIDTHS + (EMB_DIM,)
 
 
-def spmm_rows_raw(g: CsrGraph, X, rows, Z=None):
-    """(A @ X)[rows] (+ Z[rows]) as a compact [len(rows), d] tensor -- the bits of spmm_raw(g, X, Z=Z)[rows], computed for the
-    listed rows only (a training step that reads a propagated table at its batch rows).  No autograd."""
+def spmm_rows_raw(g: CsrGraph, X, rows, Z=None, z_compact=False):
+    """(A @ X)[rows] (+ Z[rows], or + Z for a compact Z [len(rows), d]) as a compact [len(rows), d] tensor -- the bits of
+    spmm_raw(g, X, Z=Z)[rows], computed for the listed rows only (a training step that reads a propagated table at its batch
+    rows).  No autograd."""
     lib = _lib.load()
     _chk(X, torch.float32, "X", 2), _chk(rows, torch.int64, "rows", 1)
     d = X.shape[1]
     if not rows_servable(g, d) or X.shape[0] < g.n_cols:
         raise _lib.MMRecHipError("spmm_rows: graph with multi-chunk rows, or X not [>=%d, 8 / 16 / 32 / 64]" % g.n_cols)
-    if Z is not None and (_chk(Z, torch.float32, "Z", 2).shape[0] < g.n_rows or Z.shape[1] != d):
-        raise _lib.MMRecHipError("Z must be [>=%d, %d]" % (g.n_rows, d))
+    if Z is not None and (_chk(Z, torch.float32, "Z", 2).shape[0] < (rows.numel() if z_compact else g.n_rows) or Z.shape[1] != d):
+        raise _lib.MMRecHipError("Z must be [>=%d, %d]" % (rows.numel() if z_compact else g.n_rows, d))
     Y = torch.empty(rows.numel(), d, dtype=torch.float32, device=X.device)
-    _lib.check(lib.mmrec_spmm_rows_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Z), _p(rows), rows.numel(), d,
-                                       g.long_row_threshold if g.n_long > 0 else 2 ** 31 - 1, _p(Y), _stream()), "spmm_rows_f32")
+    _lib.check(lib.mmrec_spmm_rows_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Z), 1 if z_compact else 0, _p(rows),
+                                       rows.numel(), d, g.long_row_threshold if g.n_long > 0 else 2 ** 31 - 1, _p(Y),
+                                       _stream()), "spmm_rows_f32")
     return Y
 
 
-def spmm_push_rows_raw(g: CsrGraph, G, rows, dX=None, dZ=None):
-    """dX[c] += A[r, c] * G[i] over the nonzeros of the listed rows r = rows[i]; dZ[r] += G[i] (fp32 atomics, in place)"""
+def spmm_push_rows_raw(g: CsrGraph, G, rows, dX=None, dZ=None, scale=1.0):
+    """dX[c] += A[r, c] * scale * G[i] over the nonzeros of the listed rows r = rows[i]; dZ[r] += scale * G[i] (fp32 atomics,
+    in place; dZ may be dX).  Any graph (one workgroup per listed row)."""
     lib = _lib.load()
     _chk(G, torch.float32, "G", 2), _chk(rows, torch.int64, "rows", 1)
     d = G.shape[1]
-    if G.shape[0] != rows.numel():
-        raise _lib.MMRecHipError("G must have one row per listed row")
+    if G.shape[0] != rows.numel() or d not in SLICE_WIDTHS + (EMB_DIM,):
+        raise _lib.MMRecHipError("G must be [len(rows), 8 / 16 / 32 / 64]")
     for t, nm, n in ((dX, "dX", g.n_cols), (dZ, "dZ", g.n_rows)):
         if t is not None and (_chk(t, torch.float32, nm, 2).shape[0] < n or t.shape[1] != d):
             raise _lib.MMRecHipError("%s must be [>=%d, %d]" % (nm, n, d))
-    _lib.check(lib.mmrec_spmm_push_rows_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(G), _p(rows), rows.numel(), d, _p(dX),
-                                            _p(dZ), _stream()), "spmm_push_rows_f32")
+    _lib.check(lib.mmrec_spmm_push_rows_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(G), float(scale), _p(rows), rows.numel(),
+                                            d, _p(dX), _p(dZ), _stream()), "spmm_push_rows_f32")
+
+
+class _SpmmRows(torch.autograd.Function):
+    """(A @ X)[rows] + Z_rows for a batch's rows (spmm_rows_raw); backward: dX by the transpose-free push through the listed
+    rows into a zero-filled table, dZ_rows = the incoming gradient"""
+
+    @staticmethod
+    def forward(ctx, X, Z_rows, g, rows):
+        ctx.g, ctx.x_shape, ctx.has_z = g, tuple(X.shape), Z_rows is not None
+        ctx.save_for_backward(rows)
+        return spmm_rows_raw(g, X.contiguous(), rows, None if Z_rows is None else Z_rows.contiguous(), z_compact=True)
+
+    @staticmethod
+    def backward(ctx, dY):
+        rows, = ctx.saved_tensors
+        dY = dY.contiguous()
+        dX = None
+        if ctx.needs_input_grad[0]:
+            dX = torch.zeros(ctx.x_shape, dtype=dY.dtype, device=dY.device)
+            spmm_push_rows_raw(ctx.g, dY, rows, dX=dX)
+        return dX, (dY if ctx.has_z and ctx.needs_input_grad[1] else None), None, None
+
+
+def spmm_rows(g: CsrGraph, X, rows, Z_rows=None):
+    """(g @ X)[rows] (+ Z_rows, compact) -- differentiable in X and Z_rows -- for a training step that reads a propagated
+    table at its batch rows only (FREEDOM's item-item layer, freedom.py:173-177 read at :197-199): the listed rows carry the
+    full launch's bits, the backward pushes through them with fp32 atomics.  `hip_deterministic` runs, and graphs with rows
+    spanning several chunks, take the full launch."""
+    if DETERMINISTIC or not rows_servable(g, X.shape[1]):
+        out = spmm(g, X).index_select(0, rows)
+        return out if Z_rows is None else out + Z_rows
+    return _SpmmRows.apply(X, Z_rows, g, rows)
 
 
 class _SpMM(torch.autograd.Function):
@@ -494,6 +529,55 @@ class _LightGCNMeanParts(torch.autograd.Function):
 def lightgcn_mean_parts(g: CsrGraph, parts, n_layers):
     """mean_l(A^l cat(parts)) as a tuple of row blocks, one per input table (freedom.py:165-178: cat, propagate, split)"""
     return _LightGCNMeanParts.apply(g, n_layers, *parts)
+
+
+class _LightGCNMeanPartsRows(torch.autograd.Function):
+    """lightgcn_mean_parts consumed at LISTED rows only (the batch's users and items): the forward is the full propagation
+    (every layer feeds the next) followed by a gather of the listed rows; the BACKWARD starts from the compact gradient of those
+    rows, so its first step -- A^T applied to a gradient that is zero outside <= 3B rows, a launch over all rows in
+    _LightGCNMean.backward -- is a push through the listed rows into a zero-filled table (one workgroup per row: popular
+    items' rows have thousands of nonzeros), and the dense [N, d] gradient of the mean never exists.  The remaining L - 1
+    steps are the usual full launches."""
+
+    @staticmethod
+    def forward(ctx, g, n_layers, rows, *parts):
+        ctx.sizes = [p.shape[0] for p in parts]
+        if row_blocks_of_one_buffer(parts):
+            E0 = parts[0].detach().as_strided((sum(ctx.sizes), parts[0].shape[1]), (parts[0].shape[1], 1))
+        else:
+            E0 = torch.cat([p.detach() for p in parts], dim=0)
+        out = _LightGCNMean.forward(ctx, E0, g, n_layers)
+        ctx.save_for_backward(rows)
+        return out.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, dRows):
+        rows, = ctx.saved_tensors
+        L, g = ctx.L, ctx.g
+        dRows = dRows.contiguous()
+        n, d = sum(ctx.sizes), dRows.shape[1]
+        s = 1.0 / (L + 1)
+        t = torch.zeros((n, d), dtype=dRows.dtype, device=dRows.device)
+        if L == 0:
+            spmm_push_rows_raw(g, dRows, rows, dZ=t)
+            return (None, None, None) + tuple(t.split(ctx.sizes))
+        # t1 = s * (A^T G + G) with G = the listed rows' gradient scattered: pushed, never materialised
+        spmm_push_rows_raw(g, dRows, rows, dX=t, dZ=t, scale=s)
+        gt = g.transpose()
+        for _ in range(1, L):          # t <- A^T t + s G
+            out = torch.empty_like(t)
+            spmm_raw(gt, t, Y=out)
+            spmm_push_rows_raw(g, dRows, rows, dZ=out, scale=s)
+            t = out
+        return (None, None, None) + tuple(t.split(ctx.sizes))
+
+
+def lightgcn_mean_parts_rows(g: CsrGraph, parts, n_layers, rows):
+    """lightgcn_mean_parts(g, parts, n_layers) read at `rows` (int64 ids in the concatenated id space) -> [len(rows), d];
+    same forward bits, the backward starts from the compact gradient (see the class).  `hip_deterministic`: the dense path."""
+    if DETERMINISTIC or parts[0].shape[1] not in SLICE_WIDTHS + (EMB_DIM,):
+        return torch.cat(lightgcn_mean_parts(g, parts, n_layers), dim=0).index_select(0, rows)
+    return _LightGCNMeanPartsRows.apply(g, n_layers, rows, *parts)
 
 
 class _LayerGCNSum(torch.autograd.Function):
@@ -649,23 +733,13 @@ class _BprLossShared(torch.autograd.Function):
     term and their sums."""
 
     @staticmethod
-    def forward(ctx, U, users, variant, scale, n_terms, joint, sum_over_ranks, pull_graph, pull_X, *flat):
+    def forward(ctx, U, users, variant, scale, n_terms, joint, sum_over_ranks, *flat):
         lib = _lib.load()
         ctx.joint = bool(joint)
         U = _chk(U.contiguous(), torch.float32, "U", 2)
         _chk(users, torch.int64, "users", 1)
         B, dev = users.numel(), U.device
         tables, ids, coefs, losses = [], [], [], []
-        ctx.pull = None
-        if pull_graph is not None:
-            # the FIRST term's table is (A @ pull_X + Z) with Z = flat[0], read at its pos / neg rows only: those 2B rows are
-            # pulled (the full launch's bits) and the term becomes (rows [2B, d], 0 .. B-1, B .. 2B-1) like the projected ones
-            Z, pos, neg = _chk(flat[0].contiguous(), torch.float32, "Z", 2), flat[1], flat[2]
-            rows = torch.cat((pos, neg))
-            ar = torch.arange(B, device=dev)
-            ctx.pull = (pull_graph, rows, tuple(Z.shape), tuple(pull_X.shape))
-            flat = (spmm_rows_raw(pull_graph, _chk(pull_X.contiguous(), torch.float32, "pull_X", 2), rows, Z), ar, ar + B) + \
-                tuple(flat[3:])
         ws = _ws(lib.mmrec_bpr_workspace_bytes(B), dev)
         d = U.shape[1]
         sliced = sum_over_ranks is not None
@@ -708,29 +782,19 @@ class _BprLossShared(torch.autograd.Function):
         U, users = saved[0], saved[1]
         tables, ids, coefs = saved[2:2 + n], saved[2 + n:2 + 3 * n], saved[2 + 3 * n:]
         dU = dI0 = None
-        pull = ctx.pull
-        first_rows = pull[2][0] if pull is not None else tables[0].shape[0]       # rows of the first term's TABLE (Z when pulled)
-        need_first = ctx.needs_input_grad[9] or (pull is not None and ctx.needs_input_grad[8])
-        if ctx.joint and ctx.needs_input_grad[0] and ctx.needs_input_grad[9]:
+        if ctx.joint and ctx.needs_input_grad[0] and ctx.needs_input_grad[7]:
             # the gradients of U and of the first item table as adjacent row blocks of one zero-filled buffer: when both
             # came out of lightgcn_mean_parts, its backward takes the buffer as the gradient of its output, copy-free
-            both = torch.zeros((U.shape[0] + first_rows, U.shape[1]), dtype=U.dtype, device=U.device)
+            both = torch.zeros((U.shape[0] + tables[0].shape[0], U.shape[1]), dtype=U.dtype, device=U.device)
             dU, dI0 = both[:U.shape[0]], both[U.shape[0]:]
         elif ctx.needs_input_grad[0]:
             dU = torch.zeros_like(U)
         out = []
-        d_pull_x = None
         for t in range(n):
             I, pos, neg = tables[t], ids[2 * t], ids[2 * t + 1]
-            need_i = ctx.needs_input_grad[9 + 3 * t] if not (t == 0 and pull is not None) else need_first
-            own = dI0 if t == 0 and dI0 is not None and pull is None else None
+            need_i = ctx.needs_input_grad[7 + 3 * t]
+            own = dI0 if t == 0 and dI0 is not None else None
             if gs[t] is None or (dU is None and not need_i):
-                if t == 0 and pull is not None:           # an unused pulled term: zero gradients of Z's and pull_X's shapes
-                    z0 = (dI0 if dI0 is not None else torch.zeros(pull[2], dtype=U.dtype, device=U.device)) \
-                        if ctx.needs_input_grad[9] else None
-                    d_pull_x = torch.zeros(pull[3], dtype=U.dtype, device=U.device) if ctx.needs_input_grad[8] else None
-                    out.extend((z0, None, None))
-                    continue
                 out.extend(((own if own is not None else torch.zeros_like(I)) if need_i else None, None, None))
                 continue
             dI = (own if own is not None else torch.zeros_like(I)) if need_i else None
@@ -740,37 +804,20 @@ class _BprLossShared(torch.autograd.Function):
             else:
                 _lib.check(lib.mmrec_bpr_bwd_f32(_p(U), _p(I), _p(I), _p(users), _p(pos), _p(neg), users.numel(), U.shape[1],
                                                  _p(coefs[t]), _p(g), ctx.scale, _p(dU), _p(dI), _p(dI), _stream()), "bpr_bwd")
-            if t == 0 and pull is not None and dI is not None:
-                # dI = gradient of the 2B pulled rows: scattered into Z's gradient at their rows, pushed through the
-                # graph's listed rows into pull_X's (no transposed graph, no launch over all rows)
-                graph, rows, z_shape, x_shape = pull
-                dZ = (dI0 if dI0 is not None else torch.zeros(z_shape, dtype=U.dtype, device=U.device)) \
-                    if ctx.needs_input_grad[9] else None
-                d_pull_x = torch.zeros(x_shape, dtype=U.dtype, device=U.device) if ctx.needs_input_grad[8] else None
-                spmm_push_rows_raw(graph, dI, rows, d_pull_x, dZ)
-                dI = dZ
             out.extend((dI, None, None))
-        return (dU, None, None, None, None, None, None, None, d_pull_x) + tuple(out)
+        return (dU, None, None, None, None, None, None) + tuple(out)
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None,
-                            pull=None):
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None):
     """[bpr_loss(U, I_t, users, pos_t, neg_t) for (I_t, pos_t, neg_t) in terms] with one shared gradient buffer for U;
     joint_grad: the gradient of the FIRST term's table is the row block right after U's in the same buffer.
     sum_over_ranks (feature-sliced layout): U and the tables are this rank's COLUMNS (8 / 16 / 32 of them, or whole rows);
     the callable sums the [terms, 2, B] partial dot products over the ranks in place (one all-reduce), the losses come out
-    replicated and every rank's backward scatters into its own columns -- the same kernels, no collective.
-    pull = (graph, X): the first term's table is `graph @ X + terms[0][0]` (FREEDOM's item-item layer with its residual,
-    freedom.py:173-177), consumed at the term's pos / neg rows only: just those rows are computed (spmm_rows_raw: the full
-    launch's bits) and the backward pushes their gradient through the listed rows (atomics; not in DETERMINISTIC mode)."""
+    replicated and every rank's backward scatters into its own columns -- the same kernels, no collective."""
     B = users.numel()
     scale = 1.0 / max(B, 1) if reduction == "mean" else 1.0
     flat = [x for term in terms for x in term]
-    graph, pull_x = pull if pull is not None else (None, None)
-    if graph is not None and (DETERMINISTIC or not rows_servable(graph, U.shape[1])):
-        flat[0] = spmm(graph, pull_x, Z=flat[0])               # the full launch (and its deterministic pull backward)
-        graph = pull_x = None
-    return _BprLossShared.apply(U, users, variant, scale, len(terms), joint_grad, sum_over_ranks, graph, pull_x, *flat)
+    return _BprLossShared.apply(U, users, variant, scale, len(terms), joint_grad, sum_over_ranks, *flat)
 
 
 def bpr_loss(U, I, users, pos, neg, variant=BPR_LOGSIG, reduction="mean"):

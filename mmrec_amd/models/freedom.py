@@ -146,15 +146,9 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
                 for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
                     if emb is not None:
                         emb.prefetch(rows)
-        pull = self.lazy_projection and self.pull_batch_rows and self.n_layers == 1
-        if pull:
-            # The item-item layer (freedom.py:173-177) is consumed at the batch's pos / neg rows only (:198-199): those 2B rows
-            # of `mm_adj @ item_emb + i_g` are pulled (same bits as the full launch) and their gradient is pushed through the
-            # listed rows -- 4096 of 500,000 rows at config 5, two full item-item launches per step gone.
-            ua, ia = hip_ops.lightgcn_mean_parts(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
-                                                 self.n_ui_layers)
-        else:
-            ua, ia = self.forward(self.masked_adj)
+        if self.lazy_projection and self.pull_batch_rows and self.n_layers == 1:
+            return self._loss_at_batch_rows(users, pos_items, neg_items, rows)
+        ua, ia = self.forward(self.masked_adj)
         self.build_item_graph = False
         if self.lazy_projection:
             # The reference projects ALL items every batch (freedom.py:205,208) but only the pos/neg rows
@@ -162,18 +156,8 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
             # feature row only, so projecting the <= 2B gathered rows is the same function and the same
             # gradient (dW, db, and dX scattered back into the table): 2.1 GFLOP regardless of n_items
             # instead of 3.7 (Baby) / 9.6 (Sports) / 262 (500K items).
-            b = pos_items.shape[0]
-            lp = torch.arange(b, device=rows.device)
-            ln = lp + b
-            gather = (lambda emb: emb.rows(rows)) if self.lazy_feature_adam else (lambda emb: emb.weight[rows])
-            terms = [(ia, pos_items, neg_items)]
-            if self.t_feat is not None:
-                terms.append((hip_ops.linear(gather(self.text_embedding), self.text_trs.weight, self.text_trs.bias), lp, ln))
-            if self.v_feat is not None:
-                terms.append((hip_ops.linear(gather(self.image_embedding), self.image_trs.weight, self.image_trs.bias), lp, ln))
-            return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, joint_grad=True,
-                                                            pull=(self.mm_adj, self.item_id_embedding.weight) if pull else None),
-                            self.t_feat is not None, self.reg_weight)
+            return _combine(hip_ops.bpr_losses_shared_users(ua, users, self._batch_terms(ia, pos_items, neg_items, rows),
+                                                            joint_grad=True), self.t_feat is not None, self.reg_weight)
         loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
         mf_t = mf_v = 0.0
         if self.t_feat is not None:
@@ -183,6 +167,38 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
             image_feats = hip_ops.linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
             mf_v = hip_ops.bpr_loss(ua, image_feats, users, pos_items, neg_items)
         return loss + self.reg_weight * (mf_t + mf_v)
+
+    def _batch_terms(self, first_table, first_pos, first_neg, rows):
+        """the three BPR terms: (id table or rows, pos ids, neg ids) + the projections of the batch's <= 2B feature rows"""
+        b = first_pos.shape[0]
+        lp = torch.arange(b, device=rows.device)
+        ln = lp + b
+        gather = (lambda emb: emb.rows(rows)) if self.lazy_feature_adam else (lambda emb: emb.weight[rows])
+        terms = [(first_table, first_pos, first_neg)]
+        if self.t_feat is not None:
+            terms.append((hip_ops.linear(gather(self.text_embedding), self.text_trs.weight, self.text_trs.bias), lp, ln))
+        if self.v_feat is not None:
+            terms.append((hip_ops.linear(gather(self.image_embedding), self.image_trs.weight, self.image_trs.bias), lp, ln))
+        return terms
+
+    def _loss_at_batch_rows(self, users, pos_items, neg_items, rows):
+        """New key `hip_pull_batch_rows` (default on; n_mm_layers = 1): the loss reads the propagated tables at the batch's
+        rows only (freedom.py:197-199), so
+          * the item-item layer (freedom.py:173-177) is computed at the 2B pos / neg rows instead of all items
+            (hip_ops.spmm_rows: the full launch's bits; 4096 of 500,000 rows at config 5) and its gradient is pushed through
+            those rows -- no launch over all items in either direction;
+          * the user-item layer mean is gathered at the 3B batch rows and its backward starts from their compact gradient
+            (hip_ops.lightgcn_mean_parts_rows): the dense [N, 64] gradient of the mean and the first of the backward's
+            launches over all rows go away.
+        Forward values are bit-identical to the full computation; the backward's pushes use fp32 atomics."""
+        b, nu = users.shape[0], self.n_users
+        at = hip_ops.lightgcn_mean_parts_rows(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
+                                              self.n_ui_layers, torch.cat((users, rows + nu)))
+        self.build_item_graph = False
+        ia_rows = hip_ops.spmm_rows(self.mm_adj, self.item_id_embedding.weight, rows, Z_rows=at[b:])
+        ar = torch.arange(b, device=rows.device)
+        return _combine(hip_ops.bpr_losses_shared_users(at[:b], ar, self._batch_terms(ia_rows, ar, ar + b, rows)),
+                        self.t_feat is not None, self.reg_weight)
 
 
 def _combine(losses, has_text, reg_weight):
@@ -630,23 +646,24 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
 
     def calculate_loss(self, interaction):
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
-        pull = self.pull_batch_rows and self.n_layers == 1      # the item-item layer at the batch rows only (see FREEDOM)
-        if pull:
-            ua, ia = hip_ops.lightgcn_mean_parts(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
-                                                 self.n_ui_layers)
-        else:
-            ua, ia = self.forward(self.masked_adj)
         rows = torch.cat((pos_items, neg_items))
         b = pos_items.shape[0]
         lp = torch.arange(b, device=rows.device)
         ln = lp + b
-        terms = [(ia, pos_items, neg_items)]
+        if self.pull_batch_rows and self.n_layers == 1:
+            # the propagated tables at the batch's rows only (FREEDOM._loss_at_batch_rows), on this rank's columns
+            at = hip_ops.lightgcn_mean_parts_rows(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
+                                                  self.n_ui_layers, torch.cat((users, rows + self.n_users)))
+            ua, users = at[:b], lp
+            terms = [(hip_ops.spmm_rows(self.mm_adj, self.item_id_embedding.weight, rows, Z_rows=at[b:]), lp, ln)]
+        else:
+            ua, ia = self.forward(self.masked_adj)
+            terms = [(ia, pos_items, neg_items)]
         if self.has_text:
             terms.append((self._owned_projection(self.text_embedding, self.text_trs, rows), lp, ln))
         if self.has_image:
             terms.append((self._owned_projection(self.image_embedding, self.image_trs, rows), lp, ln))
-        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, sum_over_ranks=self._sum_over_ranks,
-                                                        pull=(self.mm_adj, self.item_id_embedding.weight) if pull else None),
+        return _combine(hip_ops.bpr_losses_shared_users(ua, users, terms, sum_over_ranks=self._sum_over_ranks),
                         self.has_text, self.reg_weight)
 
     def _sum_over_ranks(self, t):

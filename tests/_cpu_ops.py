@@ -118,6 +118,17 @@ def spmm(g, X, Z=None):
     return y if Z is None else y + Z
 
 
+def spmm_rows(g, X, rows, Z_rows=None):
+    _ids(rows, "rows")
+    y = spmm(g, X).index_select(0, rows)
+    return y if Z_rows is None else y + Z_rows
+
+
+def lightgcn_mean_parts_rows(g, parts, n_layers, rows):
+    _ids(rows, "rows")
+    return torch.cat(lightgcn_mean_parts(g, parts, n_layers), dim=0).index_select(0, rows)
+
+
 def lightgcn_mean(g, E0, n_layers):
     _spmm_args(g, E0)
     _mat(E0, "E0", width_multiple=None if E0.shape[1] in SLICE_WIDTHS else EMB_DIM)
@@ -177,10 +188,7 @@ class _SumOverRanks(torch.autograd.Function):
         return g, None
 
 
-def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None,
-                            pull=None):
-    if pull is not None:                 # the first term's table is graph @ X + Z, consumed at the term's rows
-        terms = [(spmm(pull[0], pull[1], Z=terms[0][0]),) + tuple(terms[0][1:])] + list(terms[1:])
+def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None):
     if sum_over_ranks is None:
         return tuple(bpr_loss(U, I, users, pos, neg, variant, reduction) for I, pos, neg in terms)
     assert U.shape[1] % EMB_DIM == 0 or U.shape[1] in SLICE_WIDTHS, "slice width the kernels have"
@@ -288,7 +296,7 @@ def spmm_vals(dyn, X, vals):
     return out.index_add(0, dyn.rows, vals.unsqueeze(1) * X[dyn.cols])
 
 
-_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "lightgcn_mean", "lightgcn_mean_parts", "layergcn_sum", "layergcn_sum_parts",
+_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
             "gather_sqnorm", "cosine_mean", "linear", "score_topk", "TopkCandidates", "degree_count", "edge_norm_values",

@@ -439,15 +439,21 @@ def test_spmm_listed_rows_pull_is_bitwise_the_full_launch_and_push_is_its_transp
         assert torch.equal(got, full[rows])
     G = D(rng.standard_normal((rows.numel(), d)).astype(np.float32), dev)
     dX, dZ = torch.zeros(n, d, device=dev), torch.zeros(n, d, device=dev)
-    ops.spmm_push_rows_raw(g, G, rows, dX, dZ)
+    ops.spmm_push_rows_raw(g, G, rows, dX, dZ, scale=0.25)
     idx, val = g.to_coo_host()
     A = sp.csr_matrix((val.astype(np.float64), (idx[0], idx[1])), shape=(n, n))
     r = rows.cpu().numpy()
-    ref_x = A[r].T @ G.cpu().numpy().astype(np.float64)
+    ref_x = A[r].T @ (0.25 * G.cpu().numpy().astype(np.float64))
     ref_z = np.zeros((n, d))
-    np.add.at(ref_z, r, G.cpu().numpy().astype(np.float64))
+    np.add.at(ref_z, r, 0.25 * G.cpu().numpy().astype(np.float64))
     close(dX, ref_x, rtol=1e-5, atol=1e-5)
     close(dZ, ref_z, rtol=1e-6, atol=1e-6)
+    both = torch.zeros(n, d, device=dev)                      # dZ may be dX: A^T G + G in one buffer
+    ops.spmm_push_rows_raw(g, G, rows, both, both, scale=0.25)
+    close(both, ref_x + ref_z, rtol=1e-5, atol=1e-5)
+    zc = ops.spmm_rows_raw(g, X, rows, Z=G, z_compact=True)   # a compact residual: + Z[i]
+    plain = ops.spmm_rows_raw(g, X, rows)
+    assert torch.equal(zc, plain + G)
     # a graph with a row spanning several chunks is not served: the caller keeps the full launch
     big = ops.CsrGraph.from_coo_host(np.stack([np.zeros(2000, np.int64), rng.integers(0, 3000, 2000)]),
                                      np.ones(2000, np.float32), 3000, 3000, dev, long_row_threshold=None)
@@ -457,35 +463,45 @@ def test_spmm_listed_rows_pull_is_bitwise_the_full_launch_and_push_is_its_transp
 
 
 @pytest.mark.parametrize("d", [64, 16])
-def test_shared_user_bpr_with_pulled_item_rows_equals_the_full_item_item_launch(ops, dev, d):
-    """hip_ops.bpr_losses_shared_users(..., pull=(graph, X)): the first term's table graph @ X + Z is read at its pos / neg rows
-    only -- the losses are those of the full launch BIT FOR BIT (forward), the gradients of U, Z and X agree with the full
-    launch's autograd to rounding (push by atomics against pull sums); joint gradient buffer and a sliced width included."""
-    rng = np.random.default_rng(d)
-    g, n = _rows_test_graph(ops, dev, "knn", rng)
-    g.transpose()
-    nu, B = 700, 333
-    U0, X0, Z0 = (rng.standard_normal((m, d)).astype(np.float32) * 0.3 for m in (nu, n, n))
-    T0 = rng.standard_normal((2 * B, d)).astype(np.float32) * 0.3
-    users = torch.from_numpy(rng.integers(0, nu // 2, B)).to(dev)
-    pos, neg = (torch.from_numpy(rng.integers(0, n // 4, B)).to(dev) for _ in range(2))      # duplicates on purpose
-    lp = torch.arange(B, device=dev)
-    ln = lp + B
-    kw = dict(sum_over_ranks=(lambda t: None)) if d != 64 else dict(joint_grad=True)
+@pytest.mark.parametrize("L", [0, 1, 2, 3])
+def test_propagation_read_at_batch_rows_equals_the_dense_autograd(ops, dev, d, L):
+    """hip_ops.lightgcn_mean_parts_rows + hip_ops.spmm_rows (FREEDOM._loss_at_batch_rows): the layer mean gathered at listed
+    rows and the item-item layer pulled at listed rows == the dense ops read at those rows BIT FOR BIT in the forward; the
+    backward (compact gradient -> push through the listed rows, then L - 1 full launches) == the dense autograd to rounding.
+    A user-item graph with hub rows of thousands of nonzeros (one workgroup per pushed row), duplicated batch rows, a directed
+    20-nonzero item-item graph."""
+    rng = np.random.default_rng(10 * d + L)
+    nu, ni = 900, 400
+    from mmrec_amd import synth
+    eu, ei = synth.powerlaw_edges(nu, ni, 30_000, seed=L)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    n = nu + ni
+    g = ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
+    assert g.n_chunks > g.n_long > 0                           # rows spanning several chunks: the forward cannot be pulled here
+    mm = ops.CsrGraph.from_coo_host(np.stack([np.repeat(np.arange(ni), 20), rng.integers(0, ni, 20 * ni)]),
+                                    rng.random(20 * ni).astype(np.float32) * 0.1, ni, ni, dev, long_row_threshold=None)
+    mm.transpose()
+    U0, I0 = (rng.standard_normal((m, d)).astype(np.float32) * 0.3 for m in (nu, ni))
+    B = 257
+    users = torch.from_numpy(rng.integers(0, nu // 3, B)).to(dev)
+    items = torch.from_numpy(np.concatenate([rng.integers(0, ni // 3, 2 * B - 3), [0, 0, ni - 1]])).to(dev)
+    Gu, Gi = (D(rng.standard_normal((m, d)).astype(np.float32), dev) for m in (B, 2 * B))
 
-    def run(pulled):
-        u, x, z, t = (D(a, dev, True) for a in (U0, X0, Z0, T0))
-        if pulled:
-            ls = ops.bpr_losses_shared_users(u, users, [(z, pos, neg), (t, lp, ln)], pull=(g, x), **kw)
+    def run(rows_path):
+        u, i = D(U0, dev, True), D(I0, dev, True)
+        if rows_path:
+            at = ops.lightgcn_mean_parts_rows(g, (u, i), L, torch.cat((users, items + nu)))
+            ua_r, ia_r = at[:B], ops.spmm_rows(mm, i, items, Z_rows=at[B:])
         else:
-            ls = ops.bpr_losses_shared_users(u, users, [(ops.spmm(g, x, Z=z), pos, neg), (t, lp, ln)], **kw)
-        (ls[0] + 0.37 * ls[1]).backward()
-        return [v.detach().cpu() for v in ls], [v.grad.cpu() for v in (u, x, z, t)]
+            ua, ig = ops.lightgcn_mean_parts(g, (u, i), L)
+            ua_r, ia_r = ua[users], ops.spmm(mm, i, Z=ig)[items]
+        ((ua_r * Gu).sum() + (ia_r * Gi).sum()).backward()
+        return [x.detach().cpu() for x in (ua_r, ia_r)], [x.grad.cpu() for x in (u, i)]
 
-    (la, ga), (lb, gb) = run(True), run(False)
-    assert all(torch.equal(a, b) for a, b in zip(la, lb))
+    (fa, ga), (fb, gb) = run(True), run(False)
+    assert all(torch.equal(a, b) for a, b in zip(fa, fb))
     for a, b in zip(ga, gb):
-        close(a, b, rtol=1e-5, atol=1e-7)
+        close(a, b, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
