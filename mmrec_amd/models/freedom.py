@@ -146,7 +146,7 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
                 for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
                     if emb is not None:
                         emb.prefetch(rows)
-        if self.lazy_projection and self.pull_batch_rows and self.n_layers == 1:
+        if self.lazy_projection and self.pull_batch_rows and self.n_layers == 1 and not hip_ops.DETERMINISTIC:
             return self._loss_at_batch_rows(users, pos_items, neg_items, rows)
         ua, ia = self.forward(self.masked_adj)
         self.build_item_graph = False
@@ -650,7 +650,7 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         b = pos_items.shape[0]
         lp = torch.arange(b, device=rows.device)
         ln = lp + b
-        if self.pull_batch_rows and self.n_layers == 1:
+        if self.pull_batch_rows and self.n_layers == 1 and not hip_ops.DETERMINISTIC:
             # the propagated tables at the batch's rows only (FREEDOM._loss_at_batch_rows), on this rank's columns
             at = hip_ops.lightgcn_mean_parts_rows(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
                                                   self.n_ui_layers, torch.cat((users, rows + self.n_users)))
