@@ -80,7 +80,7 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         n_feat = max([0] + [int(f.numel()) for f in (self.v_feat, self.t_feat) if f is not None])
         self.lazy_feature_adam = lazy_adam_enabled(config, n_feat) and self.lazy_projection
         self.lazy_prefetch = config['lazy_prefetch'] is not False    # new key: catch-up on a side stream (default on)
-        self.pull_batch_rows = config['hip_pull_batch_rows'] is not False   # new key: item-item layer at the batch rows only
+        self.pull_batch_rows = _batch_rows_wanted(config, self.n_users + self.n_items)   # new key `hip_pull_batch_rows`
         self.n_nodes = self.n_users + self.n_items
 
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
@@ -199,6 +199,17 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         ar = torch.arange(b, device=rows.device)
         return _combine(hip_ops.bpr_losses_shared_users(at[:b], ar, self._batch_terms(ia_rows, ar, ar + b, rows)),
                         self.t_feat is not None, self.reg_weight)
+
+
+def _batch_rows_wanted(config, n_nodes):
+    """`hip_pull_batch_rows`: True / False, or absent / 'auto' = from 2^18 nodes on.  The batch-rows step trades launches over
+    all rows for a handful of small ones: config 5 (1.5 M nodes) 3.27 -> 2.49 ms per step, but Amazon-Sports shape 0.77 -> 0.82
+    and Amazon-Baby shape 0.89 -> 1.05 ms (cache-resident graphs whose full launches take ~10 us:
+    profiles/r04_batch_rows_small_ab.log)."""
+    v = config['hip_pull_batch_rows']
+    if v is None or str(v).lower() == 'auto':
+        return n_nodes >= (1 << 18)
+    return v is True or str(v).lower() in ('true', '1', 'yes', 'on')
 
 
 def _combine(losses, has_text, reg_weight):
@@ -547,7 +558,7 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         # are capturable; common/graph_step.py falls back to eager launches if a capture fails).  Off by default: it could only
         # be exercised on a one-rank group so far.
         self.graph_capturable = bool(config['dist_graph_step'])
-        self.pull_batch_rows = config['hip_pull_batch_rows'] is not False
+        self.pull_batch_rows = _batch_rows_wanted(config, self.n_users + self.n_items)
         nu, ni = self.n_users, self.n_items
         self.n_nodes = nu + ni
 

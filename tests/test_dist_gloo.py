@@ -420,7 +420,9 @@ def _freedom_run(root, golden, world, layout="rows"):
     from mmrec_amd.utils.utils import get_model
     from tests._env import setup
     extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "n_gpus": world, "dist_chunks": 2,
-             "dist_layout": layout}
+             "dist_layout": layout,
+             "hip_pull_batch_rows": world > 1}     # the sharded runs read the tables at the batch rows (forced: 'auto' is off at
+                                                   # this size), the single-process reference run launches over all rows
     config, train_data, valid_data = setup(root, golden, "FREEDOM", extra, use_gpu=False)
     model = get_model("FREEDOM", sharded=world > 1)(config, train_data)
     trainer = Trainer(config, model)

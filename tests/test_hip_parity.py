@@ -1521,7 +1521,8 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
         res = {}
         for sharded in (False, True):
             extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "dist_chunks": 2,
-                     "dist_force_collectives": True, "lazy_feature_adam": False, "dist_layout": layout}
+                     "dist_force_collectives": True, "lazy_feature_adam": False, "dist_layout": layout,
+                     "hip_pull_batch_rows": sharded}     # the sliced plugin at the batch rows against the plain one over all rows
             config, train_data, valid_data = setup(tmp_path / ("s%d" % sharded), golden, "FREEDOM", extra, use_gpu=True)
             model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(config["device"])
             assert type(model).__name__ == {(False, layout): "FREEDOM", (True, "rows"): "RowShardedFREEDOM",

@@ -23,6 +23,7 @@ CONFIGS = {
     "c1": ("VBPR", "baby", {"reg_weight": 1e-3}),
     "c2": ("LayerGCN", "baby", {"n_layers": 4, "dropout": 0.1, "reg_weight": 1e-3}),
     "c3": ("FREEDOM", "sports", {"dropout": 0.8, "reg_weight": 1e-3}),
+    "freedom_baby": ("FREEDOM", "baby", {"dropout": 0.8, "reg_weight": 1e-3}),
     "c4": ("BM3", "clothing", {"n_layers": 2, "dropout": 0.3, "reg_weight": 0.1}),
     "lattice": ("LATTICE", "baby", {"reg_weight": 1e-3, "learning_rate": 1e-3}),
     "lightgcn": ("LightGCN", "baby", {"n_layers": 3, "reg_weight": 1e-4}),
@@ -104,6 +105,7 @@ def main():
     ap.add_argument("--dense-adam", action="store_true", help="force the dense fused Adam on the trainable feature tables "
                                                                "(FREEDOM, BM3 default to the row-lazy exact Adam)")
     ap.add_argument("--deterministic", action="store_true", help="hip_deterministic: position-ordered gradient scatters")
+    ap.add_argument("--no-batch-rows", action="store_true", help="FREEDOM: hip_pull_batch_rows False (launches over all rows)")
     args = ap.parse_args()
     cd = dict(device_neg_sampling=args.device_neg_sampling)
     if args.graph_step or args.eager:
@@ -114,6 +116,8 @@ def main():
         cd['lazy_feature_adam'] = False
     if args.deterministic:
         cd['hip_deterministic'] = True
+    if args.no_batch_rows:
+        cd['hip_pull_batch_rows'] = False
     config, train_data, valid_data, test_data, model, _ = setup(args.config, cd, args.epochs)
     from mmrec_amd.common.trainer import Trainer
     trainer = Trainer(config, model)
