@@ -83,6 +83,12 @@ def test_argument_errors_without_gpu(lib):
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 65, None, None, None, 0, None) == 10001
     assert lib.mmrec_score_topk_f32(None, None, 4, 10, 64, None, None, 5, None, None, None, 2, None) == 10001   # unknown flag
     assert lib.mmrec_linear_fwd_f32(None, None, None, None, 4, 6, 64, None, None) == 10002  # F % 4
+    # the product at listed rows and its transposed push (ABI 10): widths 8 / 16 / 32 / 64
+    assert lib.mmrec_spmm_rows_f32(None, None, None, None, None, 0, None, 5, 128, 32, None, None) == 10002
+    assert lib.mmrec_spmm_rows_f32(None, None, None, None, None, 0, None, 5, 64, 32, None, None) == 10001
+    assert lib.mmrec_spmm_rows_f32(None, None, None, None, None, 0, None, 0, 64, 32, None, None) == 0          # empty list
+    assert lib.mmrec_spmm_push_rows_f32(None, None, None, None, 1.0, None, 5, 24, None, None, None) == 10002
+    assert lib.mmrec_spmm_push_rows_f32(None, None, None, None, 1.0, None, 5, 16, None, None, None) == 10001
     # sampled scoring on a column slice: widths 8 / 16 / 32 / 64 k, nothing else
     assert lib.mmrec_bpr_dots_f32(None, None, None, None, None, None, 5, 24, None, None) == 10002
     assert lib.mmrec_bpr_dots_f32(None, None, None, None, None, None, 5, 16, None, None) == 10001
