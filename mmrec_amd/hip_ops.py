@@ -394,7 +394,7 @@ def spmm_rows(g: CsrGraph, X, rows, Z_rows=None):
     table at its batch rows only (FREEDOM's item-item layer, freedom.py:173-177 read at :197-199): the listed rows carry the
     full launch's bits, the backward pushes through them with fp32 atomics.  `hip_deterministic` runs, and graphs with rows
     spanning several chunks, take the full launch."""
-    if DETERMINISTIC or not rows_servable(g, X.shape[1]):
+    if DETERMINISTIC or isinstance(g, PermutedGraph) or not rows_servable(g, X.shape[1]):
         out = spmm(g, X).index_select(0, rows)
         return out if Z_rows is None else out + Z_rows
     return _SpmmRows.apply(X, Z_rows, g, rows)
@@ -575,7 +575,7 @@ class _LightGCNMeanPartsRows(torch.autograd.Function):
 def lightgcn_mean_parts_rows(g: CsrGraph, parts, n_layers, rows):
     """lightgcn_mean_parts(g, parts, n_layers) read at `rows` (int64 ids in the concatenated id space) -> [len(rows), d];
     same forward bits, the backward starts from the compact gradient (see the class).  `hip_deterministic`: the dense path."""
-    if DETERMINISTIC or parts[0].shape[1] not in SLICE_WIDTHS + (EMB_DIM,):
+    if DETERMINISTIC or isinstance(g, PermutedGraph) or parts[0].shape[1] not in SLICE_WIDTHS + (EMB_DIM,):
         return torch.cat(lightgcn_mean_parts(g, parts, n_layers), dim=0).index_select(0, rows)
     return _LightGCNMeanPartsRows.apply(g, n_layers, rows, *parts)
 
