@@ -6,6 +6,10 @@
 #include "common.h"
 #include <limits.h>
 
+#ifndef MMREC_ADAM_NO_SETTLED    // probe build (tools/gpu_r4_y.sh): the catch-up always replays the full element-step
+#define MMREC_ADAM_NO_SETTLED 0
+#endif
+
 namespace {
 
 struct AdamArgs {
@@ -214,6 +218,19 @@ __global__ __launch_bounds__(256) void adam_rows_owner_kernel(const int64_t* __r
     if (i < n && ids[i] >= 0) atomicMin(owner + ids[i], i);    // id < 0: "no row" (a slot another rank serves)
 }
 
+// Can the parameter still move?  While a row is skipped its update decays by b1 / sqrt(b2) per step; once
+//     max_j |lr_j / (1 - b1^j)| * |m| / (sqrt(v) * b2^128 + eps)   (an upper bound of every update of the next <= 256 steps:
+//     |m| and v only shrink, 1 / sqrt(1 - b2^j) >= 1; 1 % slack for the hardware sqrt / rcp and the roundings)
+// is below a QUARTER ulp of p, p - update rounds to p in every one of those steps (half the spacing below p even when p is a
+// power of two): adam_decay_one leaves p's bits alone and only the two moment decays remain -- 2 instructions per element-step
+// instead of 2 + sqrt + rcp + 3.  p = 0 or denormal: never (any update moves it), unless m == 0 (no update at all).
+__device__ __forceinline__ bool adam_param_settled(float p, float m, float v, float l_max, float v_fac, float eps) {
+    if (m == 0.f) return true;
+    const float bound = 1.01f * l_max * fabsf(m) * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_sqrtf(v), v_fac, eps));
+    const float quarter_ulp = __int_as_float(__float_as_int(p) & 0x7f800000) * 2.98023224e-8f;     // 2^(e - 25)
+    return bound < quarter_ulp;
+}
+
 // ids == nullptr: every row (flush).  One workgroup per listed row.  The row stays in registers while the steps
 // are replayed (columns in tiles of 4096 floats: 4 float4 per thread); the per-step scalars come through LDS in
 // tiles of 256 steps (one global load per step and thread made the first version wait on memory 135 us per call).
@@ -222,6 +239,7 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
     int* __restrict__ owner, int F, int* __restrict__ last_step, const float2* __restrict__ hist, int t_now,
     float beta1, float beta2, float eps, float weight_decay, const long long* __restrict__ step_dev, int capacity) {
     __shared__ float2 s_h[256];
+    __shared__ float s_lmax[4];
     if (step_dev) {                                     // graph-replay form: optimizer steps taken so far, from the device
         t_now = (int)step_dev[0];
         // a step beyond the scalar table was refused by adam_hist_set_dev_kernel (sticky overflow flag, reported by the host
@@ -256,30 +274,62 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
             untouched = untouched && mm[u].x == 0.f && mm[u].y == 0.f && mm[u].z == 0.f && mm[u].w == 0.f &&
                         vv[u].x == 0.f && vv[u].y == 0.f && vv[u].z == 0.f && vv[u].w == 0.f;
         if (__syncthreads_and(untouched)) continue;
+        const float v_fac = 0.99f * powf(beta2, 128.f);         // sqrt(v) after <= 256 more decays, from below
         for (int jb = s0 + 1; jb <= t_now; jb += 256) {
             __syncthreads();
-            if (jb + (int)threadIdx.x <= t_now) s_h[threadIdx.x] = hist[jb + threadIdx.x];
-            __syncthreads();
-            const int nj = min(256, t_now - jb + 1);
-            for (int j = 0; j < nj; ++j) {
-                const float2 h = s_h[j];
-                const AdamArgs a{h.x, beta1, beta2, eps, weight_decay, h.y};
-                if (weight_decay == 0.f) {          // uniform
+            float lx = 0.f;
+            if (jb + (int)threadIdx.x <= t_now) {
+                s_h[threadIdx.x] = hist[jb + threadIdx.x];
+                lx = fabsf(s_h[threadIdx.x].x);
+            }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        adam_decay_one(pp[u].x, mm[u].x, vv[u].x, a);
-                        adam_decay_one(pp[u].y, mm[u].y, vv[u].y, a);
-                        adam_decay_one(pp[u].z, mm[u].z, vv[u].z, a);
-                        adam_decay_one(pp[u].w, mm[u].w, vv[u].w, a);
+            for (int o = 32; o >= 1; o >>= 1) lx = fmaxf(lx, __shfl_xor(lx, o, 64));
+            if ((threadIdx.x & 63) == 0) s_lmax[threadIdx.x >> 6] = lx;
+            __syncthreads();
+            const float l_max = fmaxf(fmaxf(s_lmax[0], s_lmax[1]), fmaxf(s_lmax[2], s_lmax[3]));   // largest step size of the tile
+            const int nj = min(256, t_now - jb + 1);
+            for (int j0 = 0; j0 < nj; j0 += 32) {              // 32 steps at a time: can p still move?  (per wave)
+                const int j1 = min(j0 + 32, nj);
+                bool settled = weight_decay == 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    settled = settled && adam_param_settled(pp[u].x, mm[u].x, vv[u].x, l_max, v_fac, eps) &&
+                              adam_param_settled(pp[u].y, mm[u].y, vv[u].y, l_max, v_fac, eps) &&
+                              adam_param_settled(pp[u].z, mm[u].z, vv[u].z, l_max, v_fac, eps) &&
+                              adam_param_settled(pp[u].w, mm[u].w, vv[u].w, l_max, v_fac, eps);
+                if (!MMREC_ADAM_NO_SETTLED && __all(settled)) { // the moments keep decaying, bit for bit as adam_decay_one does
+                    const float nb1 = -(1.0f - beta1);
+                    for (int j = j0; j < j1; ++j) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            mm[u].x = fmaf(nb1, mm[u].x, mm[u].x); vv[u].x = vv[u].x * beta2;
+                            mm[u].y = fmaf(nb1, mm[u].y, mm[u].y); vv[u].y = vv[u].y * beta2;
+                            mm[u].z = fmaf(nb1, mm[u].z, mm[u].z); vv[u].z = vv[u].z * beta2;
+                            mm[u].w = fmaf(nb1, mm[u].w, mm[u].w); vv[u].w = vv[u].w * beta2;
+                        }
                     }
                     continue;
                 }
+                for (int j = j0; j < j1; ++j) {
+                    const float2 h = s_h[j];
+                    const AdamArgs a{h.x, beta1, beta2, eps, weight_decay, h.y};
+                    if (weight_decay == 0.f) {          // uniform
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    adam_one(pp[u].x, 0.f, mm[u].x, vv[u].x, a);
-                    adam_one(pp[u].y, 0.f, mm[u].y, vv[u].y, a);
-                    adam_one(pp[u].z, 0.f, mm[u].z, vv[u].z, a);
-                    adam_one(pp[u].w, 0.f, mm[u].w, vv[u].w, a);
+                        for (int u = 0; u < 4; ++u) {
+                            adam_decay_one(pp[u].x, mm[u].x, vv[u].x, a);
+                            adam_decay_one(pp[u].y, mm[u].y, vv[u].y, a);
+                            adam_decay_one(pp[u].z, mm[u].z, vv[u].z, a);
+                            adam_decay_one(pp[u].w, mm[u].w, vv[u].w, a);
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        adam_one(pp[u].x, 0.f, mm[u].x, vv[u].x, a);
+                        adam_one(pp[u].y, 0.f, mm[u].y, vv[u].y, a);
+                        adam_one(pp[u].z, 0.f, mm[u].z, vv[u].z, a);
+                        adam_one(pp[u].w, 0.f, mm[u].w, vv[u].w, a);
+                    }
                 }
             }
         }

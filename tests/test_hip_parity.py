@@ -1656,6 +1656,44 @@ def test_lazy_row_adam_equals_dense(dev):
         assert torch.equal(ol, od) and opt_l.state[lazy.weight]["step"] == 12
 
 
+def test_lazy_row_adam_long_gaps_equal_dense_bitwise(dev):
+    """the catch-up's settled-parameter path (adam.hip: once the largest possible update of the next <= 256 steps is below a
+    quarter ulp of p, only the two moment decays are replayed): rows that sit out 7 ... 699 optimizer steps, parameters that
+    are exact zeros, powers of two, 1e-6-sized and ordinary, a learning-rate schedule -- every touch and the flushed table
+    == dense fused Adam BIT FOR BIT over 700 steps (parameter AND both moments)."""
+    from mmrec_amd.common.lazy_rows import LazyRowEmbedding
+    from mmrec_amd.common.optim import HipAdam
+    n, F, T = 48, 260, 700
+    g = torch.Generator().manual_seed(11)
+    w0 = torch.randn(n, F, generator=g) * 0.3
+    w0[:, ::7] = 0.0
+    w0[:, 1::7] = 0.5
+    w0[:, 2::7] *= 1e-6
+    w0[:, 3::7] = -2.0
+    gaps = torch.tensor([1, 7, 60, 150, 333, 699])[torch.arange(n) % 6]
+    dense = torch.nn.Embedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    lazy = LazyRowEmbedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    opt_d, opt_l = HipAdam([dense.weight], lr=1e-3), HipAdam([lazy.weight], lr=1e-3)
+    sch_d = torch.optim.lr_scheduler.LambdaLR(opt_d, lr_lambda=lambda ep: 0.9 ** ep)
+    sch_l = torch.optim.lr_scheduler.LambdaLR(opt_l, lr_lambda=lambda ep: 0.9 ** ep)
+    for step in range(T):
+        ids = torch.nonzero(step % gaps == 0).flatten()
+        coef = (torch.randint(-16, 17, (ids.numel(), F), generator=g).float() / 16).to(dev)
+        ids = ids.to(dev)
+        rows_l, rows_d = lazy.rows(ids), dense.weight[ids]
+        assert torch.equal(rows_l, rows_d), step
+        opt_d.zero_grad(), opt_l.zero_grad()
+        (rows_d * coef).sum().backward()
+        (rows_l * coef).sum().backward()
+        opt_d.step(), opt_l.step()
+        if step % 200 == 199:
+            sch_d.step(), sch_l.step()
+    lazy.flush()
+    assert torch.equal(lazy.weight, dense.weight)
+    for key in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(opt_l.state[lazy.weight][key], opt_d.state[dense.weight][key])
+
+
 def test_lazy_row_adam_under_graph_replay_equals_dense(dev):
     """Round-1 review item 8: the row-lazy Adam inside a REPLAYED hipGraph step.  The step-dependent scalars come from the
     capturable HipAdam's device counters (mmrec_adam_*_dev entry points), the per-step table is reserved per capture.
