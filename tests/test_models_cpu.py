@@ -241,3 +241,28 @@ def test_adjacent_id_tables_layout(tmp_path, golden):
     model.load_state_dict({k: v + 1 if k == "user_embedding.weight" else v for k, v in before.items()})
     assert hip_ops.row_blocks_of_one_buffer((model.user_embedding.weight, model.item_id_embedding.weight))
     assert torch.equal(model.user_embedding.weight.detach(), before["user_embedding.weight"] + 1)
+
+
+def test_freedom_batch_rows_step_is_the_same_function(tmp_path, golden):
+    """config `hip_pull_batch_rows`: FREEDOM's loss read at the batch rows (FREEDOM._loss_at_batch_rows: layer mean gathered at
+    cat(users, items + n_users), item-item rows with the compact residual, compact BPR terms) is the SAME function as the
+    full-table step -- loss and every gradient, on the reference's golden batch (host logic; the kernels' bits are checked on
+    the device in tests/test_hip_parity.py).  'auto' leaves graphs below 2^18 nodes on the full-table step."""
+    import torch
+    from mmrec_amd.utils.utils import get_model
+    res = {}
+    for pull in (True, False, None):
+        extra = {"dropout": 0.8, "reg_weight": 1e-3}
+        if pull is not None:
+            extra["hip_pull_batch_rows"] = pull
+        config, train_data, _ = G.setup(tmp_path / ("p%s" % pull), golden, "FREEDOM", extra, use_gpu=False)
+        model = get_model("FREEDOM")(config, train_data)
+        assert model.pull_batch_rows == bool(pull)
+        model.set_kept_edges(torch.as_tensor(golden["fr_keep_idx"]))
+        loss = model.calculate_loss(G.batch_of(golden, torch.device("cpu")))
+        loss.backward()
+        res[pull] = (float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0]) and res[None][0] == res[False][0]
+    assert set(res[True][1]) == set(res[False][1])
+    for name, ref in res[False][1].items():
+        torch.testing.assert_close(res[True][1][name], ref, rtol=1e-5, atol=1e-7, msg=name)
