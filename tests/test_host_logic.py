@@ -423,3 +423,52 @@ def test_lazy_adam_settled_parameter_bound_holds():
         expired = (settled_at >= 0) & (j + 1 >= (settled_at // 256 + 1) * 256)
         settled_at[expired] = -1
     assert (first >= 0).mean() > 0.85 and np.median(first[first >= 0]) <= 320
+
+
+@pytest.mark.parametrize("kd", [192, 384, 4096])
+def test_wide_rows_error_bound_holds(kd):
+    """The margin the wide-row path (csrc/topk_wide.h: kd = 192 ... 4096) tests its 64 approximate candidates with, restated in
+    numpy: every query row scaled by its own power of two and the candidates by one, both below 2^8, rounded to fp16, products
+    accumulated in fp32 (emulated: float32 partial sums over 16-wide k slices, as an MFMA chain accumulates):
+        |approx - exact| <= eps_q = (1.0e-3 + kd 6e-8 + 4e-6 kd / 64) |q| max|c| + 2.4e-7 sqrt(kd / 64) (|q| + max|c|)
+    in the scaled units of the approximate score (norms of the ROUNDED rows, inflated by 1.0005 as the kernel does).  Raw-
+    feature-like inputs (non-negative with a large common component), rows of very different scales, tiny elements next to a
+    dominant one."""
+    rng = np.random.default_rng(kd)
+
+    def scale_of(mx):                       # w_scale_for(): brings |x| <= mx below 2^8
+        mx = np.asarray(mx, dtype=np.float32)
+        ex = np.frexp(mx)[1]
+        return np.where(mx > 0, np.exp2(np.minimum(8.0 - ex, 120.0)), 1.0)
+
+    nq, nc = 40, 300
+    cases = []
+    base = np.maximum(rng.standard_normal((nc, kd)), 0).astype(np.float32) + 0.3
+    cases.append((base[:nq] / np.linalg.norm(base[:nq], axis=1, keepdims=True), base / np.linalg.norm(base, axis=1, keepdims=True)))
+    Q = (rng.standard_normal((nq, kd)) * 0.2).astype(np.float32)
+    for r, e in enumerate((-20, -30, -60, -100, 20)):
+        Q[r] *= np.float32(2.0) ** e
+    Q[7, 1:] *= np.float32(2.0) ** -22                       # one dominant element
+    C = (rng.standard_normal((nc, kd)) * 0.2).astype(np.float32)
+    C[:50] *= np.float32(2.0) ** -18
+    cases.append((Q, C))
+    cases.append(((rng.standard_normal((nq, kd)) * 30 + 50).astype(np.float32), (rng.standard_normal((nc, kd)) * 30 + 50).astype(np.float32)))
+    kb = kd / 64.0
+    worst = 0.0
+    for ci, (Q, C) in enumerate(cases):
+        sq = scale_of(np.abs(Q).max(axis=1)).astype(np.float32)[:, None]
+        sc = np.float32(scale_of(np.abs(C).max()))
+        Qh, Ch = (Q * sq).astype(np.float16), (C * sc).astype(np.float16)
+        assert np.isfinite(Qh).all() and np.isfinite(Ch).all()
+        acc = np.zeros((nq, nc), dtype=np.float32)
+        for k0 in range(0, kd, 16):                          # fp32 accumulation, 16 products per step
+            acc = (acc + (Qh[:, k0:k0 + 16].astype(np.float32) @ Ch[:, k0:k0 + 16].astype(np.float32).T)).astype(np.float32)
+        exact = (Q.astype(np.float64) * sq.astype(np.float64)) @ C.astype(np.float64).T * float(sc)
+        qn = np.linalg.norm(Qh.astype(np.float64), axis=1) * 1.0005
+        cmax = np.linalg.norm(Ch.astype(np.float64), axis=1).max() * 1.0005
+        eps = qn * cmax * (1.0e-3 + kd * 6.0e-8 + 4.0e-6 * kb) + 2.4e-7 * np.sqrt(kb) * (qn + cmax)
+        err = np.abs(acc.astype(np.float64) - exact).max(axis=1)
+        assert np.all(err <= eps), (ci, float((err / np.maximum(eps, 1e-300)).max()))
+        assert np.abs(acc).max() < 1e9                       # far from the -1e10 mask sentinel ("<= -1e9" reads as masked)
+        worst = max(worst, float((err[eps > 0] / eps[eps > 0]).max()))
+    assert worst > 1e-3
