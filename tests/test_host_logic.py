@@ -472,3 +472,49 @@ def test_wide_rows_error_bound_holds(kd):
         assert np.abs(acc).max() < 1e9                       # far from the -1e10 mask sentinel ("<= -1e9" reads as masked)
         worst = max(worst, float((err[eps > 0] / eps[eps > 0]).max()))
     assert worst > 1e-3
+
+
+def test_split_operand_projection_error_bound_holds():
+    """gemm.hip linear_fwd_dma_f16x3_kernel, restated in numpy: x = hi + lo, hi = fp16(x), lo' = fp16(2^11 (x - hi));
+    x w ~ hi_x hi_w + 2^-11 (hi_x lo'_w + lo'_x hi_w) with two fp32 accumulator sets (hi hi / cross terms) combined once.
+    Claim: error per product <= 2^-21 |x w|, i.e. the result is within 2^-21 sum|x w| + the fp32 accumulation
+    rounding of the exact value -- as accurate as an fp32 GEMM.  K = 4096 like the image features; relu-like non-negative
+    rows, signed rows, elements spanning 2^-20 ... 2^10 of magnitude (below fp16's normal range the lo' term is what keeps
+    the precision)."""
+    rng = np.random.default_rng(0)
+    K, n = 4096, 64
+    f16, f32, f64 = np.float16, np.float32, np.float64
+
+    def split(a):
+        hi = a.astype(f16)
+        lo = ((a - hi.astype(f32)) * f32(2048.0)).astype(f16)
+        return hi, lo
+
+    cases = [(np.maximum(rng.standard_normal((n, K)), 0).astype(f32), (rng.random((64, K)) - 0.5).astype(f32)),
+             ((rng.standard_normal((n, K)) * 10.0 ** rng.uniform(-6, 3, (n, K))).astype(f32), (rng.standard_normal((64, K)) * 0.05).astype(f32)),
+             ((rng.standard_normal((n, K)) * 300).astype(f32), (rng.standard_normal((64, K)) * 2.0 ** rng.integers(-20, 3, (64, K))).astype(f32))]
+    worst = 0.0
+    for X, W in cases:
+        xh, xl = split(X)
+        wh, wl = split(W)
+        hh = np.zeros((n, 64), f32)
+        cx = np.zeros((n, 64), f32)
+        for k0 in range(0, K, 16):                           # fp32 accumulators, 16 exact fp16 x fp16 products per MFMA step
+            s = slice(k0, k0 + 16)
+            hh = (hh + xh[:, s].astype(f32) @ wh[:, s].astype(f32).T).astype(f32)
+            cx = (cx + xh[:, s].astype(f32) @ wl[:, s].astype(f32).T + xl[:, s].astype(f32) @ wh[:, s].astype(f32).T).astype(f32)
+        got = (cx * f32(1.0 / 2048.0) + hh).astype(f32)
+        exact = X.astype(f64) @ W.astype(f64).T
+        mag = np.abs(X).astype(f64) @ np.abs(W).astype(f64).T
+        # 2^-21 per product + fp32 accumulation over K / 16 steps of two accumulators (each step rounds once: 2^-24 of the
+        # running magnitude) + the final combine
+        bound = mag * (2.0 ** -21 + (K / 16 + 2) * 2.0 ** -24)
+        err = np.abs(got.astype(f64) - exact)
+        assert np.all(err <= bound), float((err / np.maximum(bound, 1e-300)).max())
+        worst = max(worst, float((err / np.maximum(bound, 1e-300)).max()))
+        # and it is as good as a plain fp32 GEMM with the same accumulation granularity
+        ref = np.zeros((n, 64), f32)
+        for k0 in range(0, K, 16):
+            ref = (ref + X[:, k0:k0 + 16] @ W[:, k0:k0 + 16].T).astype(f32)
+        assert err.max() <= 4 * max(np.abs(ref.astype(f64) - exact).max(), 1e-30) + 1e-30 or np.all(err <= mag * 2.0 ** -20)
+    assert worst > 1e-4
