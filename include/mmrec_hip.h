@@ -240,8 +240,8 @@ int mmrec_gemm_nt_f32(const float* A, const float* B, const float* bias, float* 
  * ARGUMENT since ABI 5: the library reads no environment and keeps no state), the other shapes materialise
  * fp32-MFMA score blocks inside the workspace (topk.hip).  Unknown flag bits: MMREC_ERR_BAD_ARG.
  * ---------------------------------------------------------------------------------------------- */
-#define MMREC_TOPK_MAX 128      /* every kd % 32 == 0 (full-sort evaluations, e.g. topk: [10, 20, 50, 100]; the fp16 paths serve kd = 64 / 128 up to 128 and wider rows up to 32, the fp32 block path the rest) */
-#define MMREC_TOPK_MAX_OTHER 64 /* row widths that are not a multiple of 32 (the fused fp32 path; MMREC_ERR_UNSUPPORTED above it: callers fall back to their dense path).  ABI 9: every kd % 32 == 0 shape takes k <= 128 */
+#define MMREC_TOPK_MAX 128      /* kd % 32 == 0 AND nc <= 2,097,152 candidates (full-sort evaluations, e.g. topk: [10, 20, 50, 100]; the fp16 paths serve kd = 64 / 128 up to 128 and wider rows up to 32, the fp32 block path the rest) */
+#define MMREC_TOPK_MAX_OTHER 64 /* every other shape -- row widths that are not a multiple of 32, or more than 2,097,152 candidates -- runs the fused fp32 path, which ranks k <= 64: MMREC_ERR_UNSUPPORTED above it (callers fall back to their dense path; `strict_fused_eval` then raises) */
 #define MMREC_TOPK_NO_FILTER 1
 size_t mmrec_topk_workspace_bytes(int32_t nq, int32_t nc, int32_t kd, int32_t k);
 int mmrec_score_topk_f32(const float* Q, const float* C, int32_t nq, int32_t nc, int32_t kd,

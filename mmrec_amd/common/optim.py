@@ -97,12 +97,15 @@ class HipAdam(torch.optim.Optimizer):
             for p in group['params']:
                 table = getattr(p, '_lazy_table', None)
                 if table is not None and p in self.state and self.state[p]:
-                    # the GROUP's count: under hipGraph replay the lazy tables read the group's device counter, so a table
-                    # whose own saved count differed would replay zeroed scalar-table entries (a silent no-op)
-                    if int(self.state[p].get('step', n)) != n:
+                    own = int(self.state[p].get('step', n))
+                    if self.capturable and own != n:
+                        # under hipGraph replay the lazy tables read the GROUP's device counter, so a table whose own saved
+                        # count differed would replay zeroed scalar-table entries (a silent no-op)
                         raise ValueError('HipAdam.load_state_dict: a row-lazy table was saved at step %d, its parameter '
-                                         'group at step %d' % (int(self.state[p]['step']), n))
-                    table.resume(n)
+                                         'group at step %d' % (own, n))
+                    # eager mode: a table that saw no gradient in some steps was skipped there (as dense Adam skips a
+                    # parameter without .grad) and legitimately lags its group: it resumes at its own count
+                    table.resume(n if self.capturable else own)
 
     @torch.no_grad()
     def step(self, closure=None):

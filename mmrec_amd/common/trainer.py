@@ -71,14 +71,18 @@ class Trainer(AbstractTrainer):
         dm = config['hip_device_metrics']
         self.device_metrics = True if dm is None else bool(dm)
         self.eval_path, self.eval_paths = None, {}      # which path ranked the last evaluation / how often each one did
-        # new key: bitwise-repeatable training (position-ordered gradient scatters).  Set from the config value EVERY time a
-        # Trainer is built: the switch is process-wide (hip_ops.DETERMINISTIC), and a later Trainer of the same process --
-        # a hyper-parameter sweep, quick_start's loop -- must not inherit the previous one's choice.
+        # new keys `hip_deterministic` (bitwise-repeatable training: position-ordered gradient scatters) and `hip_linear_split`
+        # (False keeps the projection's forward on the fp32 matrix pipe).  Both switches are process-wide (hip_ops.DETERMINISTIC,
+        # hip_ops.LINEAR_F16X3) and both are set on EVERY Trainer build -- to the config value, or with the key absent to the
+        # process default hip_ops.*_DEFAULT -- so that a later Trainer of the same process (a hyper-parameter sweep,
+        # quick_start's loop) never inherits the previous run's choice.  A caller who wants a mode without a config key sets the
+        # DEFAULT (`hip_ops.DETERMINISTIC_DEFAULT = True`); the effective modes are logged.
         from mmrec_amd import hip_ops
         hip_ops.set_deterministic(hip_ops.DETERMINISTIC_DEFAULT if config['hip_deterministic'] is None
                                   else bool(config['hip_deterministic']))
-        if config['hip_linear_split'] is not None:      # new key: False keeps the projection's forward on the fp32 matrix pipe
-            hip_ops.LINEAR_F16X3 = bool(config['hip_linear_split'])
+        hip_ops.LINEAR_F16X3 = (hip_ops.LINEAR_F16X3_DEFAULT if config['hip_linear_split'] is None
+                                else bool(config['hip_linear_split']))
+        self.logger.info('hip switches: deterministic=%s linear_split=%s' % (hip_ops.DETERMINISTIC, hip_ops.LINEAR_F16X3))
 
     def _build_optimizer(self):
         kinds = {'adam': optim.Adam, 'sgd': optim.SGD, 'adagrad': optim.Adagrad, 'rmsprop': optim.RMSprop}
@@ -275,7 +279,7 @@ class Trainer(AbstractTrainer):
             why_dense = 'the model has no full_sort_topk'
         else:
             from mmrec_amd import hip_ops
-            if k > hip_ops.TOPK_MAX:             # torch.topk takes any k; the kernels 128 (64 for row widths that are not a multiple of 32: the call says so)
+            if k > hip_ops.TOPK_MAX:             # torch.topk takes any k; the kernels 128 (64 for row widths that are not a multiple of 32 or > 2M candidates: the call says so)
                 why_dense = 'max(topk) = %d > %d' % (k, hip_ops.TOPK_MAX)
         if why_dense and strict and self.fused_eval:
             raise RuntimeError('strict_fused_eval: the fused evaluation cannot serve this run (%s)' % why_dense)

@@ -122,11 +122,14 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_kernel(const float* __r
                                                                 const float* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 float* __restrict__ out, int n, int F,
-                                                                int k_chunk) {
+                                                                int k_chunk, const int* __restrict__ redo) {
     __shared__ __attribute__((aligned(1024))) float Xs0[LIN_BM * DM_BK], Xs1[LIN_BM * DM_BK], Xs2[LIN_BM * DM_BK];
     __shared__ __attribute__((aligned(1024))) float Ws0[64 * DM_BK], Ws1[64 * DM_BK], Ws2[64 * DM_BK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // fix-up launch of mmrec_linear_fwd_split_f32: only the 128-row blocks the split kernel flagged as outside its domain
+    // (redo[block]) -- or every block when a row of W is (redo[gridDim.x + row]) -- are recomputed here, in exact fp32
+    if (redo && !redo[blockIdx.x] && !__builtin_amdgcn_ballot_w64(redo[gridDim.x + lane] != 0)) return;
     const int m0 = blockIdx.x * LIN_BM;
     const int kb = blockIdx.y * k_chunk, ke = min(kb + k_chunk, F);
     const int T = (ke - kb) / DM_BK;
@@ -213,26 +216,58 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_kernel(const float* __r
 // three v_mfma_f32_32x32x16_f16 products (exact in the fp32 accumulators) instead of eight fp32 MFMAs per 16 k, two accumulator
 // sets (hi hi / cross terms) combined once at the end.  Error per product <= 2^-21 |x w| (the dropped lo lo term + the rounding
 // of lo' to 11 bits) -- the size of fp32's own accumulation error over K = 4096 terms; measured against float64 it is as
-// accurate as the fp32 kernel (tests).  Domain: |x|, |w| < 32768 (fp16 range; a feature table or a weight of that size is a bug
-// upstream; `hip_ops.LINEAR_F16X3 = False` / config `hip_linear_split: False` keep the fp32 kernel).
+// accurate as the fp32 kernel (tests).
+// DOMAIN, and what happens outside it (nothing silent): the split is exact to 2^-22 |x| only while fp16 holds both parts.
+//   * |x| or |w| >= 65520 (or inf / NaN): hi is inf, the products are inf / NaN -> the OUTPUT is non-finite.
+//   * 0 < |x| < 2^-14: hi is an fp16 subnormal and lo' cannot hold what it drops: absolute error 2^-36 per element, which is
+//     harmless next to elements of ordinary size in the same row (error 2^-36 |w_k| against a sum of size |x_k'| |w_k'|) and NOT
+//     harmless in a row whose every element is tiny (relative error 1e-4 at |x| ~ 1e-7, 1e-2 at 1e-8).
+//   The kernel therefore tracks max |x| per row (one v_max3 per two elements) and looks at its own outputs; a 128-row block
+//   with a non-finite output or a row with 0 < max |x| < 2^-10 sets redo[block], linear_w_split_kernel sets redo[last] for a
+//   W row with 0 < max |w| < 2^-10, and a second launch -- the fp32 kernel, which returns at once for blocks that are not
+//   flagged -- recomputes those blocks in exact fp32: inf / NaN propagate as F.linear's do, tiny rows get fp32's relative
+//   accuracy.  No host synchronisation, capture-safe; the guarantee for unflagged rows is
+//   |err| <= 2^-21 sum |x w| + 2^-25 max|x_row| sum |w_row|  (the second term: <= 2^-36 per tiny element, row max >= 2^-10).
 // X streams through the same LDS-DMA ring as linear_fwd_dma_kernel (fp32 tiles, split in registers: ~6 VALU per element, about
 // the time of the 12 MFMAs they feed); W is split ONCE per call into the workspace in the tile layout the DMA wants (per 32-k
 // block and row: 32 hi halves | 32 lo' halves = the same 128 B as the fp32 tile row).  Bound: the HBM stream of X.
 typedef __attribute__((ext_vector_type(8))) _Float16 g_half8;
 
-__global__ __launch_bounds__(256) void linear_w_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wsp) {
-    // one thread per (row, 32-k block): 32 floats in, 32 hi halves + 32 lo' halves out
-    const int blocks = F / 32, t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= 64 * blocks) return;
-    const int row = t / blocks, kb = t % blocks;
-    const float* src = W + (size_t)row * F + kb * 32;
-    _Float16* dst = reinterpret_cast<_Float16*>(Wsp + (size_t)row * F + kb * 32);
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-        const float w = src[k];
-        const _Float16 hi = (_Float16)w;
-        dst[k] = hi;
-        dst[32 + k] = (_Float16)((w - (float)hi) * 2048.f);
+constexpr float SPLIT_ROW_MIN = 0x1p-10f;    // a row (of X or W) whose largest |element| is below this, and not 0, is recomputed in fp32
+
+// grid 64 (one workgroup per W row): a thread splits 8 consecutive floats at a time (two 16-B loads, coalesced across the
+// workgroup) into 8 hi halves + 8 lo' halves of the row's tile layout; redo[0 .. nblocks) = 0 (workgroup 0),
+// redo[nblocks + row] = 1 if W row `row` leaves the split's small-magnitude domain.
+__global__ __launch_bounds__(256) void linear_w_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wsp,
+                                                             int* __restrict__ redo, int nblocks) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    if (row == 0)
+        for (int j = threadIdx.x; j < nblocks; j += 256) redo[j] = 0;
+    float mx = 0.f;
+    for (int e8 = threadIdx.x; e8 < F / 8; e8 += 256) {            // F % 32 == 0
+        const int kb = e8 >> 2, sub = (e8 & 3) * 8;
+        const float4* src = reinterpret_cast<const float4*>(W + (size_t)row * F + kb * 32 + sub);
+        const float4 a = src[0], b = src[1];
+        const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        g_half8 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hi[k] = (_Float16)w[k];
+            lo[k] = (_Float16)((w[k] - (float)hi[k]) * 2048.f);
+            mx = fmaxf(mx, fabsf(w[k]));
+        }
+        _Float16* dst = reinterpret_cast<_Float16*>(Wsp + (size_t)row * F + kb * 32);
+        *reinterpret_cast<g_half8*>(dst + sub) = hi;
+        *reinterpret_cast<g_half8*>(dst + 32 + sub) = lo;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        redo[nblocks + row] = (mx > 0.f && mx < SPLIT_ROW_MIN) ? 1 : 0;
     }
 }
 
@@ -241,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const floa
                                                                       const float* __restrict__ Wsp,
                                                                       const float* __restrict__ bias,
                                                                       float* __restrict__ out, int n, int F,
-                                                                      int k_chunk) {
+                                                                      int k_chunk, float* __restrict__ rowmax_part,
+                                                                      int* __restrict__ redo) {
     __shared__ __attribute__((aligned(1024))) float Xs0[LIN_BM * DM_BK], Xs1[LIN_BM * DM_BK], Xs2[LIN_BM * DM_BK];
     __shared__ __attribute__((aligned(1024))) float Ws0[64 * DM_BK], Ws1[64 * DM_BK], Ws2[64 * DM_BK];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -272,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const floa
     };
     const int i = lane & 31, h = lane >> 5, g = (i >> 1) & 7;
     f32x16 hh0 = {0}, hh1 = {0}, cx0 = {0}, cx1 = {0};      // hi x hi and cross-term accumulators of the two 32-output tiles
+    float xmax = 0.f;                                       // max |x| over this lane's half of row 32 wave + i (domain check)
     auto compute = [&](const float* xs, const float* ws) {
         const float* xa = xs + (32 * wave + i) * DM_BK;
         const float* wb = ws + i * DM_BK;
@@ -288,6 +325,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const floa
                 ah[e] = hi;
                 al[e] = (_Float16)((xv[e] - (float)hi) * 2048.f);
             }
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) xmax = fmaxf(fmaxf(xmax, fabsf(xv[e])), fabsf(xv[e + 1]));     // v_max3_f32 |.|, |.|
             const int ch = ((2 * st + h) ^ g) << 2, cl = ((4 + 2 * st + h) ^ g) << 2;     // hi / lo' chunks of the W tile row
             const g_half8 bh0 = *reinterpret_cast<const g_half8*>(wb + ch), bl0 = *reinterpret_cast<const g_half8*>(wb + cl);
             const g_half8 bh1 = *reinterpret_cast<const g_half8*>(wb + 32 * DM_BK + ch);
@@ -316,13 +355,26 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const floa
     float* dst = out + (size_t)blockIdx.y * n * 64;
     const float b0 = (bias && gridDim.y == 1) ? bias[i] : 0.f;
     const float b1 = (bias && gridDim.y == 1) ? bias[32 + i] : 0.f;
+    bool bad = false;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wave * 32 + d_row(r, lane);
         if (row < n) {
-            dst[(size_t)row * 64 + i] = fmaf(cx0[r], 1.f / 2048.f, hh0[r]) + b0;
-            dst[(size_t)row * 64 + 32 + i] = fmaf(cx1[r], 1.f / 2048.f, hh1[r]) + b1;
+            const float y0 = fmaf(cx0[r], 1.f / 2048.f, hh0[r]) + b0, y1 = fmaf(cx1[r], 1.f / 2048.f, hh1[r]) + b1;
+            dst[(size_t)row * 64 + i] = y0;
+            dst[(size_t)row * 64 + 32 + i] = y1;
+            bad |= !(fabsf(y0) < __builtin_inff()) | !(fabsf(y1) < __builtin_inff());      // inf or NaN
         }
+    }
+    // domain check (see the comment above the kernel): the two lane halves hold the two k halves of row 32 wave + i
+    xmax = fmaxf(xmax, __shfl_xor(xmax, 32));
+    if (gridDim.y == 1) {
+        bad |= xmax > 0.f && xmax < SPLIT_ROW_MIN;
+        if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) redo[blockIdx.x] = 1;       // every writer stores the same 1
+    } else {                                            // the row's maximum over the slabs is taken by slab_reduce_kernel
+        const int row = m0 + wave * 32 + i;
+        if (h == 0 && row < n) rowmax_part[(size_t)blockIdx.y * n + row] = xmax;
+        if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) redo[blockIdx.x] = 1;
     }
 }
 
@@ -330,7 +382,9 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const floa
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int nslab,
                                                           size_t slab_elems,
                                                           const float* __restrict__ bias,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out,
+                                                          const float* __restrict__ rowmax_part = nullptr,
+                                                          int* __restrict__ redo = nullptr) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_elems) return;
     // four independent chains keep the slab loads in flight (a single chain of up to 64 dependent
@@ -347,6 +401,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     float4 t = f4_add(f4_add(t0, t1), f4_add(t2, t3));
     if (bias) t = f4_add(t, reinterpret_cast<const float4*>(bias)[i4 & 15]);
     reinterpret_cast<float4*>(out)[i4] = t;
+    if (redo) {     // split-operand forward (64 columns = 16 threads per row): non-finite sums, rows of tiny magnitude -> redo in fp32
+        const float inf = __builtin_inff();
+        bool bad = !(fabsf(t.x) < inf) | !(fabsf(t.y) < inf) | !(fabsf(t.z) < inf) | !(fabsf(t.w) < inf);
+        const size_t row = i4 >> 4, nrows = slab_elems >> 6;
+        if ((i4 & 15) == 0) {
+            float mx = 0.f;
+            for (int q = 0; q < nslab; ++q) mx = fmaxf(mx, rowmax_part[(size_t)q * nrows + row]);
+            bad |= mx > 0.f && mx < SPLIT_ROW_MIN;
+        }
+        if (bad) redo[row / LIN_BM] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------- backward W
@@ -595,8 +660,10 @@ extern "C" size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out
     int s1, c1, s2, c2;
     pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &s1, &c1);
     pick_split(ceil_div(F, BW_BF), n, BW_BK, &s2, &c2);
-    // forward: partial slabs, then (mmrec_linear_fwd_split_f32) the 64 x F split copy of W
-    const size_t fwd = ((s1 > 1 ? (size_t)s1 * n * 64 * sizeof(float) : 0) + 255) / 256 * 256 + (size_t)64 * F * sizeof(float);
+    // forward: partial slabs, then (mmrec_linear_fwd_split_f32) the 64 x F split copy of W, the per-slab row maxima of |X| and
+    // the redo flags of its domain check (one per 128-row block + one per W row)
+    const size_t fwd = ((s1 > 1 ? (size_t)s1 * n * 64 * sizeof(float) : 0) + 255) / 256 * 256 + (size_t)64 * F * sizeof(float) +
+                       (s1 > 1 ? (size_t)s1 * n * sizeof(float) : 0) + ((size_t)ceil_div(n, LIN_BM) + 64) * sizeof(int);
     const size_t bww = ((s2 > 1 ? (size_t)s2 * 64 * F : 0) + (size_t)s2 * 64) * sizeof(float);
     return fwd > bww ? fwd : bww;
 }
@@ -621,9 +688,9 @@ extern "C" int mmrec_linear_fwd_f32(const float* X, const float* W, const float*
     // X larger than the 256 MB Infinity Cache is read once per call: stream it non-temporal
     const bool nt = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);
     if (dma && nt)
-        hipLaunchKernelGGL(linear_fwd_dma_kernel<true>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk);
+        hipLaunchKernelGGL(linear_fwd_dma_kernel<true>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk, (const int*)nullptr);
     else if (dma)
-        hipLaunchKernelGGL(linear_fwd_dma_kernel<false>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk);
+        hipLaunchKernelGGL(linear_fwd_dma_kernel<false>, grid, dim3(256), 0, s, X, W, b, dst, n, F, chunk, (const int*)nullptr);
     else
         hipLaunchKernelGGL(linear_fwd_kernel<MMREC_GEMM_PROBE_MODE>, grid, dim3(256),
                            MMREC_GEMM_DYN_LDS, s, X, W, b, dst, n, F, chunk);
@@ -637,7 +704,9 @@ extern "C" int mmrec_linear_fwd_f32(const float* X, const float* W, const float*
 }
 
 // mmrec_linear_fwd_f32 on the 16-bit matrix cores with split operands (fp32-accurate: see linear_fwd_dma_f16x3_kernel).  F % 32 != 0
-// takes the fp32 kernels.  Workspace: mmrec_linear_workspace_bytes (the split copy of W lives behind the partial slabs).
+// takes the fp32 kernels.  Rows / weights outside the split's domain (|.| >= 65520, inf, NaN, or a whole row below 2^-10) are
+// detected on the device and recomputed by the fp32 kernel in the same call (no host synchronisation): see the kernel's comment.
+// Workspace: mmrec_linear_workspace_bytes (slabs | split W | per-slab row maxima | redo flags).
 extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const float* b, float* Y, int32_t n, int32_t F,
                                           int32_t out, void* workspace, mmrec_stream_t stream) {
     if (out != 64 || F <= 0 || (F & 3)) return MMREC_ERR_UNSUPPORTED;
@@ -648,22 +717,30 @@ extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const 
     int nsplit, chunk;
     pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &nsplit, &chunk);
     hipStream_t s = mmrec_stream(stream);
+    const int nblocks = ceil_div(n, LIN_BM);
     float* part = static_cast<float*>(workspace);
     float* Wsp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
                                           ((nsplit > 1 ? (size_t)nsplit * n * 64 * sizeof(float) : 0) + 255) / 256 * 256);
-    hipLaunchKernelGGL(linear_w_split_kernel, dim3(ceil_div(64 * (F / 32), 256)), dim3(256), 0, s, W, F, Wsp);
+    float* rowmax_part = Wsp + (size_t)64 * F;
+    int* redo = reinterpret_cast<int*>(rowmax_part + (nsplit > 1 ? (size_t)nsplit * n : 0));
+    hipLaunchKernelGGL(linear_w_split_kernel, dim3(64), dim3(256), 0, s, W, F, Wsp, redo, nblocks);
     float* dst = nsplit == 1 ? Y : part;
-    const dim3 grid(ceil_div(n, LIN_BM), nsplit);
+    const dim3 grid(nblocks, nsplit);
     const bool nt = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);
     if (nt)
-        hipLaunchKernelGGL(linear_fwd_dma_f16x3_kernel<true>, grid, dim3(256), 0, s, X, Wsp, b, dst, n, F, chunk);
+        hipLaunchKernelGGL(linear_fwd_dma_f16x3_kernel<true>, grid, dim3(256), 0, s, X, Wsp, b, dst, n, F, chunk, rowmax_part, redo);
     else
-        hipLaunchKernelGGL(linear_fwd_dma_f16x3_kernel<false>, grid, dim3(256), 0, s, X, Wsp, b, dst, n, F, chunk);
+        hipLaunchKernelGGL(linear_fwd_dma_f16x3_kernel<false>, grid, dim3(256), 0, s, X, Wsp, b, dst, n, F, chunk, rowmax_part, redo);
     if (nsplit > 1) {
         const size_t elems = (size_t)n * 64;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, part, nsplit, elems,
-                           b, Y);
+                           b, Y, (const float*)rowmax_part, redo);
     }
+    // fix-up: the fp32 kernel over the flagged 128-row blocks (the others return at once), whole K per workgroup
+    if (nt)
+        hipLaunchKernelGGL(linear_fwd_dma_kernel<true>, dim3(nblocks, 1), dim3(256), 0, s, X, W, b, Y, n, F, F, (const int*)redo);
+    else
+        hipLaunchKernelGGL(linear_fwd_dma_kernel<false>, dim3(nblocks, 1), dim3(256), 0, s, X, W, b, Y, n, F, F, (const int*)redo);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

@@ -18,46 +18,17 @@
 #include "common.h"
 #include "spmm_narrow.h"
 
-// tools/spmm_lab.py builds this file with a cache-policy mask (the library only ever uses MMREC_SPMM_POLICY below):
-// bit0 colidx / vals streamed with nontemporal loads, bit1 Y / acc written with nontemporal stores, bit2 X rows gathered
-// with nontemporal loads.  (Measured, profiles/r02_spmm_cache_policy_lab.log: bits 0 / 1 change nothing, bit 2 costs 50 %;
-// a per-column hot / cold split -- nontemporal gathers for unpopular columns only -- cost 60 %:
-// profiles/r02_spmm_lab_hot_cold_nontemporal.log.)
-#ifndef MMREC_SPMM_LAB
-#define MMREC_SPMM_LAB 0
-#endif
 // matrix rows per 16-lane group of a row block (tools/spmm_sweep.py overrides it)
 #ifndef MMREC_SPMM_RPG
 #define MMREC_SPMM_RPG(n_rows) ((n_rows) <= (1 << 18) ? 1 : 4)
 #endif
-// rows of a group walked TOGETHER when rows-per-group equals this (0 / 1: one after the other), X rows prefetched per row
-#ifndef MMREC_SPMM_RB
-#define MMREC_SPMM_RB 0
-#define MMREC_SPMM_PF 4
-#endif
+// Measured and NOT in this file (logs under profiles/, code in the history): nontemporal loads of colidx / vals and nontemporal
+// stores of Y change nothing, nontemporal X gathers cost 50 %, a hot / cold column split 60 % (r02_spmm_cache_policy_lab.log,
+// r02_spmm_lab_hot_cold_nontemporal.log); walking the rows of a group together with their gathers prefetched is bit-identical
+// and slower on every graph (r04_spmm_rows_batched_lab_*.log, last present at commit 3e827a9); LDS staging of the most
+// popular X rows: tools/spmm_lds_hot_lab.hip, profiles/r05_spmm_lds_hot_lab.log.
 
 namespace {
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_x(const float4* p) {
-    if (MMREC_SPMM_LAB & 4) {
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    return *p;
-}
-__device__ __forceinline__ void st_y(float4* p, float4 y) {
-    if (MMREC_SPMM_LAB & 2) {
-        v4f v = {y.x, y.y, y.z, y.w};
-        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
-    } else {
-        *p = y;
-    }
-}
-template <typename T>
-__device__ __forceinline__ T ld_stream(const T* p) {
-    return (MMREC_SPMM_LAB & 1) ? __builtin_nontemporal_load(p) : *p;
-}
 
 // Partial sums that another workgroup of the SAME launch reads (the last-arriver row finish below): written and read with
 // agent-scope accesses (sc1: through the XCD's L2 to the device's coherence point), so that no L2 write-back /
@@ -105,12 +76,12 @@ __device__ __forceinline__ void store_row(const RowEpilogue& ep, int row, int la
         const float ng = fmaxf(sqrtf(row16_sum(f4_dot(g, g))), 1e-8f);
         const float w = dot / (ne * ng);
         const float4 o = f4_scale(w, y);
-        if (ep.Y) st_y(reinterpret_cast<float4*>(ep.Y) + off, y);
-        st_y(reinterpret_cast<float4*>(ep.scaled) + off, o);
+        if (ep.Y) reinterpret_cast<float4*>(ep.Y)[off] = y;
+        reinterpret_cast<float4*>(ep.scaled)[off] = o;
         if (lane16 == 0) ep.w_out[row] = w;
         if (ep.acc_out)
-            st_y(reinterpret_cast<float4*>(ep.acc_out) + off,
-                 ep.acc_in ? f4_add(reinterpret_cast<const float4*>(ep.acc_in)[off], o) : o);
+            reinterpret_cast<float4*>(ep.acc_out)[off] =
+                ep.acc_in ? f4_add(reinterpret_cast<const float4*>(ep.acc_in)[off], o) : o;
         return;
     }
 #pragma unroll
@@ -118,10 +89,10 @@ __device__ __forceinline__ void store_row(const RowEpilogue& ep, int row, int la
         const size_t off = (size_t)row * (16 * DCH) + ch * 16 + lane16;  // float4 index
         float4 y = f4_scale(ep.alpha, sum[ch]);
         if (ep.Z) y = f4_fma(ep.beta, reinterpret_cast<const float4*>(ep.Z)[off], y);
-        if (ep.Y) st_y(reinterpret_cast<float4*>(ep.Y) + off, y);
+        if (ep.Y) reinterpret_cast<float4*>(ep.Y)[off] = y;
         if (ep.acc_out) {
             const float4 a = reinterpret_cast<const float4*>(ep.acc_in)[off];
-            st_y(reinterpret_cast<float4*>(ep.acc_out) + off, f4_scale(ep.acc_scale, f4_add(a, y)));
+            reinterpret_cast<float4*>(ep.acc_out)[off] = f4_scale(ep.acc_scale, f4_add(a, y));
         }
     }
 }
@@ -139,8 +110,8 @@ __device__ __forceinline__ void gather_span(const int32_t* __restrict__ colidx,
         int c = 0;
         float v = 0.f;
         if (k < e) {
-            c = ld_stream(colidx + k);
-            v = ld_stream(vals + k);
+            c = colidx[k];
+            v = vals[k];
         }
         const int cnt = min(16, e - base);
         // up to 8 gathers in flight per group per step (latency hiding for long-ish rows on small,
@@ -155,7 +126,7 @@ __device__ __forceinline__ void gather_span(const int32_t* __restrict__ colidx,
                 vv[u] = __shfl(v, j, 16);
 #pragma unroll
                 for (int ch = 0; ch < DCH; ++ch)
-                    x[u][ch] = (j < cnt) ? ld_x(X4 + (size_t)cj * (16 * DCH) + ch * 16 + lane16) : f4_zero();
+                    x[u][ch] = (j < cnt) ? X4[(size_t)cj * (16 * DCH) + ch * 16 + lane16] : f4_zero();
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u)
@@ -195,88 +166,10 @@ __device__ __forceinline__ void reduce_long_row(const float* __restrict__ partia
     }
 }
 
-// The RB short rows of a 16-lane group TOGETHER (d = 64): the row kernel's chain per row is rowptr -> (col, val) -> X rows ->
-// store, three dependent memory round trips, and a group that walks its rows one after the other exposes all of them per
-// row -- the pruned training graph of config 5 (4M nnz over 1.5M rows: 2.7 per row) ran at half the rate of the 13-per-row
-// headline graph (profiles/r04_spmm_rows_batched.log).  Here the RB row extents are read at once, then the first 16
-// (col, val) pairs of every row, then the first PF X rows of every row (RB x PF gathers in flight per group); the rest of a
-// row, if any, follows row by row as before.  A row's terms are added in the same order as ever: same bits.
-template <int RB, int PF, bool LG>
-__device__ __forceinline__ void rows_batched(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                             const float* __restrict__ vals, const float4* __restrict__ X4,
-                                             const RowEpilogue& ep, int n_rows, int long_t, int row0, int lane16) {
-    int s[RB], n[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int row = row0 + i * 16;
-        s[i] = 0;
-        n[i] = -1;                               // no such row
-        if (row < n_rows) {
-            s[i] = rowptr[row];
-            n[i] = rowptr[row + 1] - s[i];
-        }
-    }
-    int c[RB];
-    float v[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        if (n[i] > long_t) n[i] = -1;            // handled by the chunk blocks
-        c[i] = 0;
-        v[i] = 0.f;
-        if (lane16 < n[i]) {
-            c[i] = ld_stream(colidx + s[i] + lane16);
-            v[i] = ld_stream(vals + s[i] + lane16);
-        }
-    }
-    // EVERY X-row load below is unconditional -- a slot past the row's end re-reads the row's last column (an L1 hit; column
-    // 0 for an empty row) and a select drops the value: with `(u < n) ? load : 0` the compiler put each load into its own
-    // branch and, in the loop, drained it (s_waitcnt vmcnt(0)) before issuing the next one.
-    float4 x[RB][PF];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int last = max(min(n[i], 16), 1) - 1;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int cj = __shfl(c[i], min(u, last), 16);
-            x[i][u] = ld_x(X4 + (size_t)cj * 16 + lane16);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        if (n[i] < 0) continue;                  // uniform within the group
-        float4 acc[1] = {f4_zero()};
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {           // (slots past the end: v = 0 there, and the select keeps a non-finite X row out)
-            const float4 xu = (u < n[i]) ? x[i][u] : f4_zero();
-            acc[0] = f4_fma(__shfl(v[i], u, 16), xu, acc[0]);
-        }
-        const int cnt = min(16, n[i]);
-        for (int j0 = PF; j0 < cnt; j0 += 8) {   // the rest of the first window, 8 gathers in flight
-            float4 y[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int cj = __shfl(c[i], min(j0 + u, cnt - 1), 16);
-                y[u] = ld_x(X4 + (size_t)cj * 16 + lane16);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                const float vv = (j < 16) ? __shfl(v[i], j & 15, 16) : 0.f;
-                acc[0] = f4_fma(vv, (j < cnt) ? y[u] : f4_zero(), acc[0]);
-            }
-        }
-        if (n[i] > 16) gather_span<1>(colidx, vals, X4, s[i] + 16, s[i] + n[i], lane16, acc);
-        store_row<1, LG>(ep, row0 + i * 16, lane16, acc);
-    }
-}
-
 // One launch covers both kinds of work: blocks [0, n_chunks) reduce one long-row chunk each (started
 // first: they are the longest dependency chains), blocks [n_chunks, ...) process 64 short rows each.
-#ifndef MMREC_SPMM_WAVES    // tools/spmm_rows_lab.py: minimum waves per SIMD the register allocator must leave room for (0: its choice)
-#define MMREC_SPMM_WAVES 0
-#endif
 template <int DCH, bool LG>
-__global__ __launch_bounds__(256, (DCH == 1 && !LG && MMREC_SPMM_WAVES) ? MMREC_SPMM_WAVES : 1) void spmm_rows_kernel(
+__global__ __launch_bounds__(256) void spmm_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
     const float* __restrict__ vals, const float* __restrict__ X, RowEpilogue ep, int n_rows,
     int long_t, int rows_per_group, const int32_t* __restrict__ long_rows,
@@ -351,11 +244,6 @@ __global__ __launch_bounds__(256, (DCH == 1 && !LG && MMREC_SPMM_WAVES) ? MMREC_
         return;
     }
     const int row0 = ((int)blockIdx.x - n_chunks) * 16 * rows_per_group + g;
-    if (DCH == 1 && MMREC_SPMM_RB > 1 && rows_per_group == MMREC_SPMM_RB) {
-        rows_batched<(MMREC_SPMM_RB > 1 ? MMREC_SPMM_RB : 2), MMREC_SPMM_PF, LG>(rowptr, colidx, vals, X4, ep, n_rows, long_t, row0,
-                                                                             lane16);
-        return;
-    }
 #pragma unroll 1
     for (int i = 0; i < rows_per_group; ++i) {
         const int row = row0 + i * 16;

@@ -19,8 +19,11 @@ from . import _lib
 EMB_DIM = 64
 # The 4096 -> 64 projection's forward on the 16-bit matrix cores with split operands (x = hi + 2^-11 lo' in fp16, three fp16 MFMA
 # products per 16 k; as accurate against float64 as the fp32-MFMA kernel, which is bound by the 1/16-rate fp32 matrix pipe and
-# not by the stream of X).  Domain |x|, |w| < 32768.  False (config `hip_linear_split: False`): the fp32 kernel.
-LINEAR_F16X3 = True
+# not by the stream of X).  Rows / weights outside fp16's range -- |.| >= 65520, inf, NaN, a whole row below 2^-10 -- are found on
+# the device and recomputed by the fp32 kernel inside the same call (csrc/gemm.hip), so the result is fp32-accurate over all of
+# fp32's range.  False (config `hip_linear_split: False`): the fp32 kernel for everything.
+LINEAR_F16X3_DEFAULT = True       # what `hip_linear_split: null` means (the Trainer applies the config value on every build)
+LINEAR_F16X3 = LINEAR_F16X3_DEFAULT
 SLICE_WIDTHS = (8, 16, 32)    # one feature slice of a 64-wide table: 64 / P columns per rank of the feature-sliced layout (csrc/spmm_narrow.hip)
 SPMM_CHUNK = 512
 LONG_ROW_DEFAULT = None    # by graph size, see default_long_row_threshold
@@ -38,7 +41,7 @@ def default_long_row_threshold(n_cols):
         return int(forced)
     return 16 if n_cols <= (1 << 18) else 32
 
-TOPK_MAX = 128            # MMREC_TOPK_MAX: every row width that is a multiple of 32; 64 for the others (the library says so)
+TOPK_MAX = 128            # MMREC_TOPK_MAX: row widths that are a multiple of 32 with <= 2,097,152 candidates; 64 for every other shape (the library says so: MMREC_ERR_UNSUPPORTED)
 BPR_LOGSIG, BPR_GAMMA = 0, 1
 
 # `hip_deterministic` (config key; Trainer sets it): the backward scatters of the fused loss kernels (BPR, cosine, InfoNCE,

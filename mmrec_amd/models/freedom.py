@@ -43,7 +43,11 @@ def load_or_build_mm_coo(config, v_feat, t_feat, knn_k, mm_image_weight, n_items
         return torch.load(cache, weights_only=False)
     mm = build_mm_adj(v_feat, t_feat, knn_k, mm_image_weight, n_items)
     if write:
-        torch.save(mm.cpu(), cache)
+        # written under a temporary name and renamed into place: the ranks of a multi-process run all come through here
+        # (every rank builds the same graph, rank 0 writes), and a rank that finds the file must never read a half-written one
+        tmp = '%s.tmp.%d' % (cache, os.getpid())
+        torch.save(mm.cpu(), tmp)
+        os.replace(tmp, cache)
     return mm
 
 

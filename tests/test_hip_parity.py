@@ -796,6 +796,106 @@ def test_linear_split_forward_is_as_accurate_as_the_fp32_kernel(ops, dev, n, F):
     assert torch.equal(out[True][3], out[False][3])              # the zero row: bias only, exactly
 
 
+@pytest.mark.parametrize("n,F", [(1000, 4096), (7050, 384), (40_000, 4096), (300_000, 128)])
+def test_linear_split_domain_guard(ops, dev, n, F):
+    """The split-operand forward is the DEFAULT projection, so it has to be a drop-in for fp32 `nn.Linear` (freedom.py:205,208;
+    bm3.py:102-104) over ALL of fp32's range, not only where fp16 holds the two halves: rows of tiny magnitude (1e-7, 1e-8: fp16
+    subnormals), of huge magnitude (5e4 < 65504 still inside; 1e5, 3e38 outside), inf and NaN.  No bias, error measured against
+    sum |x_k w_k| ALONE (a bias of size 1 would hide a 1e-6-scaled row), <= 1e-6; non-finite rows propagate exactly as the
+    fp32 kernel's (= F.linear's) do; rows in the same 128-row block as a flagged row and all other rows are unharmed.  Shapes:
+    one slab per row block (40,000 x 4096; 300,000 x 128) and split-K (1000 x 4096, 7050 x 384: maxima combined over slabs)."""
+    g = torch.Generator().manual_seed(n + F)
+    X = torch.relu(torch.randn(n, F, generator=g))
+    W = torch.randn(64, F, generator=g) / F ** 0.5
+    scales = {1: 1e-7, 2: 1e-8, 5: 5e4, 130: 1e5, 260: 3e-5, 261: 1e-3, 400: 1e-12, 520: 1e-30}
+    for r, sc in scales.items():
+        X[r] *= sc
+    X[390, 7] = 3e38                      # finite in fp32 and so is 3e38 * w: fp16's inf must not reach the result
+    X[650] = 0.0                          # an all-zero row is exact in both kernels and must not be flagged
+    X[651, :] = 0.0
+    X[651, F - 1] = 1e-9                  # a single tiny element
+    X[700, 3] = float("inf")
+    X[701, 5] = float("nan")
+    X[702, 0], X[702, 1] = float("inf"), -float("inf")
+    Xd, Wd = X.to(dev), W.to(dev)
+    out = {}
+    try:
+        for split in (True, False):
+            ops.LINEAR_F16X3 = split
+            out[split] = ops.linear(Xd, Wd, None).cpu()
+    finally:
+        ops.LINEAR_F16X3 = True
+    finite = torch.isfinite(X).all(1)
+    ref = X[finite].double() @ W.double().t()
+    scale = X[finite].double().abs() @ W.double().abs().t()
+    for k in (True, False):
+        err = ((out[k][finite].double() - ref).abs() / (scale + 1e-300))
+        err[scale == 0] = (out[k][finite].double() - ref).abs()[scale == 0]
+        assert torch.isfinite(out[k][finite]).all()
+        assert float(err.max()) <= 1e-6, (k, float(err.max()), int(err.max(1)[0].argmax()))
+    # non-finite rows: the flagged blocks ARE the fp32 kernel's result (same nan / inf pattern as F.linear)
+    bad = ~finite
+    tr = torch.nn.functional.linear(X[bad], W)
+    assert torch.equal(torch.isnan(out[True][bad]), torch.isnan(tr)) and torch.equal(torch.isinf(out[True][bad]), torch.isinf(tr))
+    assert torch.equal(torch.isnan(out[True][bad]), torch.isnan(out[False][bad]))
+    assert torch.equal(out[True][650], torch.zeros(64))
+
+
+def test_linear_split_domain_guard_weights(ops, dev):
+    """The same guard on W's side: a weight row of tiny magnitude (or a huge / non-finite weight) sends the whole call to the fp32
+    kernel; with ordinary weights nothing is recomputed and the two kernels differ only at the 1e-7 level."""
+    g = torch.Generator().manual_seed(5)
+    n, F = 2000, 4096
+    X = torch.relu(torch.randn(n, F, generator=g))
+    for mod in ("tiny_row", "huge", "nan", "mixed_small"):
+        W = torch.randn(64, F, generator=g) / F ** 0.5
+        if mod == "tiny_row":
+            W[17] *= 1e-7
+        elif mod == "huge":
+            W[3, 100] = 1e5
+        elif mod == "nan":
+            W[9, 0] = float("nan")
+        else:
+            W[:, ::3] *= 1e-9           # tiny elements inside rows of ordinary size: stays on the split kernel, error norm-wise small
+        out = {}
+        try:
+            for split in (True, False):
+                ops.LINEAR_F16X3 = split
+                out[split] = ops.linear(X.to(dev), W.to(dev), None).cpu()
+        finally:
+            ops.LINEAR_F16X3 = True
+        if mod == "nan":
+            assert torch.isnan(out[True][:, 9]).all() and torch.isfinite(out[True][:, :9]).all()
+            continue
+        ref = X.double() @ W.double().t()
+        scale = X.double().abs() @ W.double().abs().t()
+        # 'huge': one product of 1e5 |x| sits among 4095 of ~5e-3 -- every later addition rounds at ulp(1e5): ANY fp32 accumulation
+        # chain is off by ~sqrt(K) 2^-24 of the sum there (the flagged call runs the fp32 kernel with the whole K per workgroup)
+        tol = 2e-5 if mod == "huge" else 1e-6
+        for k in (True, False):
+            assert float(((out[k].double() - ref).abs() / scale).max()) <= tol, (mod, k)
+
+
+def test_linear_split_guard_is_capture_safe(ops, dev):
+    """The guard decides on the device (flags in the workspace, a second launch that returns at once): the call can be captured
+    in a hipGraph and replayed on inputs that flip a block in and out of the domain."""
+    g = torch.Generator().manual_seed(11)
+    X = torch.relu(torch.randn(1500, 4096, generator=g)).to(dev)
+    W = (torch.randn(64, 4096, generator=g) / 64).to(dev)
+    Y = ops.linear(X, W, None)                      # warm-up (workspace allocation) outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        Y = ops.linear(X, W, None)
+    for scale in (1.0, 1e-8, 1.0, 2e5):
+        X[200].normal_(generator=None).abs_().mul_(scale)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = X.double().cpu() @ W.double().cpu().t()
+        sc = X.double().cpu().abs() @ W.double().cpu().abs().t()
+        assert float(((Y.double().cpu() - ref).abs() / sc).max()) <= 1e-6, scale
+
+
 @pytest.mark.parametrize("n,F,out,bias", [(300, 96, 256, True), (1000, 256, 256, False), (129, 384, 384, True),
                                           (777, 4096, 256, True)])
 def test_linear_wide_fwd_bwd(ops, dev, n, F, out, bias):
@@ -1406,13 +1506,13 @@ def test_spmm_baby_shape_vs_oracle(ops, dev):
     g = ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True)
     rng = np.random.default_rng(0)
     X = (rng.random((n, 64), dtype=np.float32) - 0.5) * 0.2
-    import scipy.sparse as sp
-    A = sp.csr_matrix((v, (r, c)), shape=(n, n), dtype=np.float32)
-    cur, ref = torch.from_numpy(X).to(dev), X
+    # the oracle's reference-form operand: the UNCOALESCED row-sorted COO the reference multiplies by (freedom.py:113-126,172)
+    adj = orc.sparse_coo(np.stack([r, c]), v, n)
+    cur, ref = torch.from_numpy(X).to(dev), torch.from_numpy(X)
     for _ in range(3):
         Y = torch.empty_like(cur)
         ops.spmm_raw(g, cur, Y=Y)
-        ref = A @ ref
+        ref = torch.sparse.mm(adj, ref)
         cur = Y
     assert rel_fro(cur, ref) < 1e-6
     close(cur, ref, atol=1e-7)
@@ -1452,6 +1552,22 @@ def test_spmm_c5_properties(ops, dev):
         s, e = rp[row], rp[row + 1]
         ref = (v[s:e].astype(np.float64)[:, None] * Xh[c[s:e]]).sum(0)
         np.testing.assert_allclose(Yh[row], ref, rtol=1e-4, atol=1e-6)
+    # EXHAUSTIVE: all 1.5 M rows of the layer against a float64-accumulating CSR product on the host (torch CPU), each element
+    # within 1e-4 relative of the row's sum |a_k x_k| scale (north_star's tolerance; fp32 summation of <= 143k terms observed
+    # ~1e-6), and the oracle's own reference-form product (fp32 torch.sparse.mm on the uncoalesced COO) to the same bound
+    A64 = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(c.astype(np.int64)), torch.from_numpy(v.astype(np.float64)),
+                                  size=(n, n))
+    ref64 = (A64 @ torch.from_numpy(Xh)).numpy()
+    Aabs = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(c.astype(np.int64)), torch.from_numpy(np.abs(v).astype(np.float64)),
+                                   size=(n, n))
+    scale = (Aabs @ torch.from_numpy(np.abs(Xh))).numpy()
+    err = np.abs(Yh.astype(np.float64) - ref64)
+    worst = float((err / (scale + 1e-30)).max())
+    print("spmm c5, all %d rows: max |err| / sum|a x| = %.3e" % (n, worst))
+    assert worst < 1e-5, worst                                      # 10 x inside north_star's 1e-4
+    assert np.all(err <= 1e-4 * np.abs(ref64) + 1e-5 * scale)       # element-wise relative, cancellation-safe
+    ref32 = torch.sparse.mm(orc.sparse_coo(np.stack([r, c]), v, n), X.cpu()).numpy()
+    assert float((np.abs(Yh - ref32) / (scale + 1e-30)).max()) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------- RCCL path

@@ -518,3 +518,61 @@ def test_split_operand_projection_error_bound_holds():
             ref = (ref + X[:, k0:k0 + 16] @ W[:, k0:k0 + 16].T).astype(f32)
         assert err.max() <= 4 * max(np.abs(ref.astype(f64) - exact).max(), 1e-30) + 1e-30 or np.all(err <= mag * 2.0 ** -20)
     assert worst > 1e-4
+
+
+def test_split_operand_projection_domain_rule():
+    """The device-side guard of mmrec_linear_fwd_split_f32 (gemm.hip: SPLIT_ROW_MIN, redo flags), restated in numpy.  Rule: a row
+    whose largest |x| is below 2^-10 (and not 0), or whose split result is non-finite, is recomputed by the fp32 kernel.  Shown
+    here: (i) the rule is NEEDED -- rows scaled by 1e-7 / 1e-8 are wrong by > 1e-5 of sum |x w| in the raw split, and |x| >= 65520
+    turns into inf / NaN although the fp32 product is finite; (ii) the rule is SUFFICIENT -- every row it does not flag meets
+    |err| <= 2^-21 sum |x w| + 2^-25 max|x_row| sum |w_row| + fp32 accumulation, tiny elements inside ordinary rows included."""
+    rng = np.random.default_rng(1)
+    K, n = 4096, 48
+    f16, f32, f64 = np.float16, np.float32, np.float64
+    ROW_MIN = f32(2.0 ** -10)
+
+    def split(a):
+        with np.errstate(over="ignore", invalid="ignore"):
+            hi = a.astype(f16)
+            lo = ((a - hi.astype(f32)) * f32(2048.0)).astype(f16)
+        return hi, lo
+
+    X = np.maximum(rng.standard_normal((n, K)), 0).astype(f32)
+    scale = np.ones(n)
+    scale[:12] = [1e-7, 1e-8, 1e-5, 3e-4, 2e-3, 1e-2, 1e2, 1e4, 1.5e4, 1e5, 1e-12, 1e-30]
+    X = (X * scale[:, None]).astype(f32)
+    X[12, ::2] *= f32(1e-9)                       # an ordinary row, half of whose elements are tiny
+    X[13, 1:] *= f32(1e-9)                        # one ordinary element, the rest tiny
+    X[13, 0] = 1.0
+    X[14] = 0
+    W = (rng.standard_normal((64, K)) / 64).astype(f32)
+    xh, xl = split(X)
+    wh, wl = split(W)
+    with np.errstate(over="ignore", invalid="ignore"):
+        hh = np.zeros((n, 64), f32)
+        cx = np.zeros((n, 64), f32)
+        for k0 in range(0, K, 16):
+            s = slice(k0, k0 + 16)
+            hh = (hh + xh[:, s].astype(f32) @ wh[:, s].astype(f32).T).astype(f32)
+            cx = (cx + xh[:, s].astype(f32) @ wl[:, s].astype(f32).T + xl[:, s].astype(f32) @ wh[:, s].astype(f32).T).astype(f32)
+        got = (cx * f32(1.0 / 2048.0) + hh).astype(f32)
+    exact = X.astype(f64) @ W.astype(f64).T
+    mag = np.abs(X).astype(f64) @ np.abs(W).astype(f64).T
+    rowmax = np.abs(X).max(1)
+    flagged = ((rowmax > 0) & (rowmax < ROW_MIN)) | ~np.isfinite(got).all(1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(got.astype(f64) - exact) / mag
+    # (i) needed
+    print("raw split error / sum|xw| by row:", rel.max(1)[:15])
+    assert flagged[0] and flagged[1] and rel[0].max() > 2e-6 and rel[1].max() > 2e-5
+    assert flagged[9] and not np.isfinite(got[9]).all() and np.isfinite(exact[9]).all()      # 1e5 * relu-normal: some |x| > 65504
+    assert flagged[10] and flagged[11] and flagged[2]
+    assert not flagged[3:9].any() and not flagged[12:].any()      # 3e-4 x relu-normal: row max 1.2e-3, just inside
+    # (ii) sufficient
+    ok = ~flagged
+    bound = mag * (2.0 ** -21 + (K / 16 + 2) * 2.0 ** -24) + 2.0 ** -25 * rowmax[:, None] * np.abs(W).astype(f64).sum(1)[None, :]
+    err = np.abs(got.astype(f64) - exact)
+    assert np.all(err[ok] <= bound[ok])
+    assert np.nanmax(rel[ok & (rowmax > 0)]) <= 1e-6                         # the test the device suite applies
+    assert np.array_equal(got[14], np.zeros(64, f32))
+

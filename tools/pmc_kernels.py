@@ -67,12 +67,30 @@ SPMM_SETS = [
 ]
 
 
+def graphs(dev):
+    """the three SpMM operands of a config-5 step: the full user-item graph, its 80 %-pruned training graph, an item-item kNN-like graph"""
+    import numpy as np
+    from mmrec_amd import hip_ops, synth
+    out = {}
+    nu, ni, eu, ei = synth.shaped_edges("c5", seed=0)
+    n = nu + ni
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    out["c5_full_20M"] = (hip_ops.CsrGraph.from_coo_host(np.stack([r, c]), v, n, n, dev, symmetric=True), n)
+    rng = np.random.default_rng(0)
+    keep = np.sort(rng.choice(eu.shape[0], eu.shape[0] // 5, replace=False))
+    r2, c2, v2 = synth.sym_norm_coo(eu[keep], ei[keep], nu, ni)
+    out["c5_pruned_4M"] = (hip_ops.CsrGraph.from_coo_host(np.stack([r2, c2]), v2, n, n, dev, symmetric=True), n)
+    rows = np.repeat(np.arange(ni), 20)
+    cols = rng.integers(0, ni, rows.shape[0])
+    out["c5_item_item_10M"] = (hip_ops.CsrGraph.from_coo_host(np.stack([rows, cols]), np.full(rows.shape[0], 0.05, np.float32),
+                                                              ni, ni, dev), ni)
+    return out
+
+
 def child_spmm():
     import torch
     sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
     from mmrec_amd import hip_ops
-    from spmm_rows_lab import graphs
     dev = torch.device("cuda:0")
     for name, (g, n_x) in graphs(dev).items():
         for d in (64, 32, 8):
