@@ -77,6 +77,55 @@ def mask_to_csr_device(mask, n_rows, n_cols):
     return rowptr.to(torch.int32), (key - rows * n_cols).to(torch.int32)
 
 
+# ---- build-time relabelling for gather locality (config key `reorder`) -----------------------------
+class BipartiteRelabelling:
+    """A relabelling of the users and of the items of ONE dataset (`reorder`: 'community' | 'degree' | 'rcm';
+    hip_ops.locality_order on the symmetric user-item graph, then each side ranked on its own so that users stay a block and
+    items stay a block -- the two id tables stay two tables).  `perm_*[old] = new`, `inv_*[new] = old` (device int64).
+
+    A model that keeps its tables in the relabelled space pays NOTHING per step for the locality (hip_ops.PermutedGraph pays
+    two permutation passes over [N, 64] per propagation: more than a 3-layer propagation gains): ids are mapped where they
+    enter the model (a batch's [3, B] ids, an evaluation batch's users and mask), graphs are relabelled once at build time
+    with every row's nonzeros kept in their original order (relabel_graph: same sums, bit for bit), top-K ids and the
+    state_dict leave in the ORIGINAL ids."""
+
+    def __init__(self, base_graph, n_users, n_items, how, device):
+        n = n_users + n_items
+        idx, _ = base_graph.to_coo_host()
+        perm = hip_ops.locality_order(base_graph.rowptr_host, idx[1], n, how, n_left=n_users)
+        self.how, self.n_users, self.n_items = how, int(n_users), int(n_items)
+        pu = np.argsort(np.argsort(perm[:n_users], kind="stable"), kind="stable").astype(np.int64)   # rank among the users
+        pi = np.argsort(np.argsort(perm[n_users:], kind="stable"), kind="stable").astype(np.int64)
+        self.perm_u_host, self.perm_i_host = pu, pi
+        self.perm_u, self.perm_i = torch.from_numpy(pu).to(device), torch.from_numpy(pi).to(device)
+        self.inv_u, self.inv_i = torch.argsort(self.perm_u), torch.argsort(self.perm_i)
+
+    def node_perm_host(self):
+        return np.concatenate([self.perm_u_host, self.n_users + self.perm_i_host])
+
+    def to(self, device):
+        for k in ("perm_u", "perm_i", "inv_u", "inv_i"):
+            setattr(self, k, getattr(self, k).to(device))
+        return self
+
+
+def relabel_graph(g, row_perm_host, col_perm_host=None):
+    """CsrGraph with rows (and columns) renamed, every row's nonzeros in their ORIGINAL order (stable COO -> CSR): the row sums
+    are the plain graph's bit for bit.  A non-symmetric graph's transpose is relabelled from the plain transpose for the same
+    reason (the backward's sums keep their order too)."""
+    col_perm_host = row_perm_host if col_perm_host is None else col_perm_host
+
+    def one(src, rp, cp, symmetric):
+        idx, val = src.to_coo_host()
+        return hip_ops.CsrGraph.from_coo_host(np.stack([rp[idx[0]], cp[idx[1]]]), val, src.n_rows, src.n_cols, src.rowptr.device,
+                                              symmetric=symmetric, long_row_threshold=src.long_row_threshold)
+    out = one(g, row_perm_host, col_perm_host, g.symmetric)
+    if not g.symmetric:
+        t = one(g.transpose(), col_perm_host, row_perm_host, False)
+        out._t, t._t = t, out
+    return out
+
+
 # ---- the reference's on-disk graph caches (SURVEY.md 8f4) -----------------------------------------
 def dense_adj_to_coo(adj):
     """LATTICE caches its kNN graphs as DENSE [I, I] tensors (`image_adj_{k}.pt`, lattice.py:64-87).

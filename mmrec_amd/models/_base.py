@@ -55,24 +55,86 @@ class FusedEvalMixin:
             self._eval_cands = hip_ops.TopkCandidates(i)
         return u, self._eval_cands
 
+    # A model whose tables live in a RELABELLED id space (config `reorder`, RelabelledIdsMixin) maps ids where they enter and
+    # leave; for every other model these are the identity.
+    relabelling = None
+
     def full_sort_predict(self, interaction):
         u, i = self._cached_eval_embeddings()
-        return torch.matmul(u[interaction[0]], i.transpose(0, 1))
+        rl = self.relabelling
+        if rl is None:
+            return torch.matmul(u[interaction[0]], i.transpose(0, 1))
+        # columns back in the ORIGINAL item order (the reference Trainer indexes them with the dataset's ids)
+        return torch.matmul(u[rl.perm_u[interaction[0]]], i.transpose(0, 1)).index_select(1, rl.perm_i)
 
     @torch.no_grad()
     def full_sort_topk(self, interaction, k):
         users, mask = interaction[0], interaction[1]
         u, cands = self._cached_eval_candidates()
         i = cands.C if isinstance(cands, hip_ops.TopkCandidates) else cands
+        rl = self.relabelling
         cache = getattr(interaction, 'cache', None)          # our EvalDataLoader: batches never change
-        key = ('mask_csr', getattr(interaction, 'cache_key', None), i.shape[0])
+        key = ('mask_csr', getattr(interaction, 'cache_key', None), i.shape[0], None if rl is None else rl.how)
         if cache is not None and key in cache:
             rowptr, cols = cache[key]
         else:
+            if rl is not None and mask.shape[1]:
+                mask = torch.stack([mask[0], rl.perm_i[mask[1]]])
             rowptr, cols = mask_to_csr_device(mask, users.shape[0], i.shape[0])
             if cache is not None:
                 cache[key] = (rowptr, cols)
-        return hip_ops.score_topk(u[users].contiguous(), cands, k, rowptr, cols)
+        if rl is None:
+            return hip_ops.score_topk(u[users].contiguous(), cands, k, rowptr, cols)
+        # ranked in the relabelled space (ties between EXACTLY equal scores go to the lower relabelled id), reported in the dataset's ids
+        return rl.inv_i[hip_ops.score_topk(u[rl.perm_u[users]].contiguous(), cands, k, rowptr, cols)]
+
+
+class RelabelledIdsMixin:
+    """New config key `reorder: community | degree | rcm` (absent / null: off): the model keeps its id-indexed tables -- the
+    user / item id embeddings, the raw feature tables and their Adam state -- in an id space relabelled ONCE at build time for
+    gather locality (graph.BipartiteRelabelling), so the locality costs nothing per step.  What the plugin API sees is
+    unchanged: `calculate_loss` / `full_sort_predict` / `full_sort_topk` take and return the dataset's ids, `state_dict()`
+    holds every table in the ORIGINAL row order (a reference checkpoint loads, and a checkpoint written here loads into the
+    reference), and results equal the plain model's -- per-row sums bit for bit (rows keep their nonzero order).
+    Subclasses list their tables in `relabelled_tables = {parameter name: 'u' | 'i'}` and call `_map_batch` on the way in."""
+
+    relabelled_tables = {}
+
+    def _map_batch(self, interaction):
+        rl = self.relabelling
+        if rl is None:
+            return interaction
+        rows = [rl.perm_u[interaction[0]]] + [rl.perm_i[interaction[j]] for j in range(1, interaction.shape[0])]
+        return torch.stack(rows)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self.relabelling is not None:
+            dev = next(self.parameters()).device
+            self.relabelling.to(dev)
+        return out
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        rl = self.relabelling
+        if rl is not None:
+            prefix = kwargs.get('prefix', '')
+            for name, side in self.relabelled_tables.items():
+                k = prefix + name
+                if k in sd:                                # original row `old` = relabelled row perm[old]
+                    perm = rl.perm_u if side == 'u' else rl.perm_i
+                    sd[k] = sd[k].detach().index_select(0, perm.to(sd[k].device))
+        return sd
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        rl = self.relabelling
+        if rl is not None:
+            state_dict = dict(state_dict)
+            for name, side in self.relabelled_tables.items():
+                if name in state_dict:                     # relabelled row `new` = original row inv[new]
+                    inv = rl.inv_u if side == 'u' else rl.inv_i
+                    state_dict[name] = state_dict[name].index_select(0, inv.to(state_dict[name].device))
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
 
 class AdjacentTablesMixin:

@@ -18,8 +18,9 @@ import torch.nn as nn
 
 from mmrec_amd import hip_ops
 from mmrec_amd.common.lazy_rows import LazyRowEmbedding, lazy_adam_enabled
-from mmrec_amd.graph import knn_normalized_coo, mask_to_csr_device, norm_adj_graph, sparse_coo_to_graph
-from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender
+from mmrec_amd.graph import (BipartiteRelabelling, knn_normalized_coo, mask_to_csr_device, norm_adj_graph, relabel_graph,
+                             sparse_coo_to_graph)
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
 
 
 def build_mm_adj(v_feat, t_feat, knn_k, mm_image_weight, n_items):
@@ -58,10 +59,12 @@ def load_or_build_mm_adj(config, v_feat, t_feat, knn_k, mm_image_weight, n_items
     return g
 
 
-class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
+class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
 
     adjacent_tables = ('user_embedding.weight', 'item_id_embedding.weight')
+    relabelled_tables = {'user_embedding.weight': 'u', 'item_id_embedding.weight': 'i', 'image_embedding.weight': 'i',
+                         'text_embedding.weight': 'i'}
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -89,28 +92,48 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
 
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
         self.norm_adj = norm_adj_graph(self.interaction_matrix, self.n_users, self.n_items, self.device)
+        # new key `reorder` (community | degree | rcm): every id-indexed table lives in an id space relabelled once, here, for
+        # gather locality (models/_base.py: RelabelledIdsMixin); the graphs are relabelled with their rows' nonzero order kept
+        how = config['reorder']
+        self.relabelling = rl = (BipartiteRelabelling(self.norm_adj, self.n_users, self.n_items, str(how).lower(), self.device)
+                                 if how and str(how).lower() not in ('none', 'false', 'off') else None)
+        if rl is not None:
+            self.norm_adj = relabel_graph(self.norm_adj, rl.node_perm_host())
         self.masked_adj, self.mm_adj = None, None
         rows = torch.from_numpy(self.interaction_matrix.row.astype(np.int64))
         cols = torch.from_numpy(self.interaction_matrix.col.astype(np.int64))
         self.edge_indices = torch.stack([rows, cols]).to(self.device)
+        # (degrees, hence the values, do not depend on the labels; the EDGE ORDER -- what torch.multinomial draws from in
+        # pre_epoch_processing -- is the dataset's either way)
         self.edge_values = hip_ops.edge_norm_values(self.edge_indices[0].contiguous(),
                                                     self.edge_indices[1].contiguous(),
                                                     self.n_users, self.n_items)
+        if rl is not None:
+            self.edge_indices = torch.stack([rl.perm_u[self.edge_indices[0]], rl.perm_i[self.edge_indices[1]]])
 
         self.user_embedding = nn.Embedding(self.n_users, self.embedding_dim)
         self.item_id_embedding = nn.Embedding(self.n_items, self.embedding_dim)
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_id_embedding.weight)
+        if rl is not None:            # the plain model's initial values, row `old` at relabelled row perm[old]
+            with torch.no_grad():
+                self.user_embedding.weight.copy_(self.user_embedding.weight[rl.inv_u.cpu()])
+                self.item_id_embedding.weight.copy_(self.item_id_embedding.weight[rl.inv_i.cpu()])
         table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
+        in_space = (lambda f: f) if rl is None else (lambda f: f.index_select(0, rl.inv_i.to(f.device)))
         if self.v_feat is not None:
-            self.image_embedding = table.from_pretrained(self.v_feat, freeze=False)
+            self.image_embedding = table.from_pretrained(in_space(self.v_feat), freeze=False)
             self.image_trs = nn.Linear(self.v_feat.shape[1], self.feat_embed_dim)
         if self.t_feat is not None:
-            self.text_embedding = table.from_pretrained(self.t_feat, freeze=False)
+            self.text_embedding = table.from_pretrained(in_space(self.t_feat), freeze=False)
             self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
 
+        # (built / loaded in the dataset's ids: the cache file `mm_adj_freedomdsp_*.pt` is the reference's, and kNN ties are
+        # broken by id)
         self.mm_adj = load_or_build_mm_adj(config, self.v_feat, self.t_feat, self.knn_k, self.mm_image_weight,
                                            self.n_items, self.device)
+        if rl is not None:
+            self.mm_adj = relabel_graph(self.mm_adj, rl.perm_i_host)
 
     def _build_mm_adj(self):
         return build_mm_adj(self.v_feat, self.t_feat, self.knn_k, self.mm_image_weight, self.n_items)
@@ -142,6 +165,7 @@ class FREEDOM(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         return self.forward(self.norm_adj)
 
     def calculate_loss(self, interaction):
+        interaction = self._map_batch(interaction)
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
         rows = None
         if self.lazy_projection:

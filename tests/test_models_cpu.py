@@ -266,3 +266,64 @@ def test_freedom_batch_rows_step_is_the_same_function(tmp_path, golden):
     assert set(res[True][1]) == set(res[False][1])
     for name, ref in res[False][1].items():
         torch.testing.assert_close(res[True][1][name], ref, rtol=1e-5, atol=1e-7, msg=name)
+
+
+@pytest.mark.parametrize("how", ["community", "degree", "rcm"])
+def test_freedom_relabelled_id_space_is_the_same_model(tmp_path, golden, how):
+    """config `reorder`: FREEDOM keeps every id-indexed table in an id space relabelled once at build time (graph.BipartiteRelabelling
+    / models/_base.py: RelabelledIdsMixin); what the plugin API sees is the plain model: same initial state_dict (original row
+    order), same loss on the reference's golden batch (the graphs keep every row's nonzero order, so the sums are the same
+    sums), same gradients after un-permuting, same full-sort scores / top-K in the dataset's ids, and a state_dict round trip
+    between the two.  With / without the batch-rows step and the gathered-rows projection."""
+    import torch
+    from mmrec_amd.utils.utils import get_model
+    for variant in ({}, {"hip_pull_batch_rows": True}, {"lazy_projection": False}):
+        res = {}
+        for key in (None, how):
+            extra = dict({"dropout": 0.8, "reg_weight": 1e-3}, **variant)
+            if key:
+                extra["reorder"] = key
+            config, train_data, valid_data = G.setup(tmp_path / ("r%s%d" % (key, len(res))), golden, "FREEDOM", extra, use_gpu=False)
+            model = get_model("FREEDOM")(config, train_data).to("cpu")
+            assert (model.relabelling is not None) == bool(key)
+            sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+            model.set_kept_edges(torch.as_tensor(golden["fr_keep_idx"]))
+            loss = model.calculate_loss(G.batch_of(golden, torch.device("cpu")))
+            loss.backward()
+            grads = {}
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                gr = p.grad.clone()
+                side = model.relabelled_tables.get(n)
+                if key and side:                   # gradient row of ORIGINAL id `old` sits at relabelled row perm[old]
+                    gr = gr.index_select(0, model.relabelling.perm_u if side == "u" else model.relabelling.perm_i)
+                grads[n] = gr
+            model.eval()
+            batch = next(iter(valid_data))
+            res[key] = dict(model=model, sd0=sd0, loss=float(loss.detach()), grads=grads, batch=batch,
+                            topk=model.full_sort_topk(batch, 20).clone(), scores=model.full_sort_predict(batch).clone())
+        a, b = res[None], res[how]
+        rl = b["model"].relabelling
+        assert sorted(rl.perm_u.tolist()) == list(range(rl.perm_u.numel())) and sorted(rl.perm_i.tolist()) == list(range(rl.perm_i.numel()))
+        if how != "community":          # (label propagation on this tiny dense graph ends with one label: the identity is a valid answer)
+            assert not torch.equal(rl.perm_u, torch.arange(rl.perm_u.numel()))
+        assert list(a["sd0"]) == list(b["sd0"])
+        for k in a["sd0"]:
+            assert torch.equal(a["sd0"][k], b["sd0"][k]), k
+        assert a["loss"] == b["loss"], (variant, a["loss"], b["loss"])
+        assert set(a["grads"]) == set(b["grads"])
+        for n, ref in a["grads"].items():
+            torch.testing.assert_close(b["grads"][n], ref, rtol=1e-5, atol=1e-8, msg=n)
+        torch.testing.assert_close(b["scores"], a["scores"], rtol=1e-6, atol=1e-7)
+        assert torch.equal(a["topk"], b["topk"])
+        # checkpoints travel both ways
+        trained = {k: v + 0.01 * torch.arange(v.shape[0]).reshape([-1] + [1] * (v.dim() - 1)) if v.dim() else v
+                   for k, v in a["sd0"].items()}
+        a["model"].load_state_dict(trained)
+        b["model"].load_state_dict(trained)
+        for k, v in b["model"].state_dict().items():
+            assert torch.equal(v, a["model"].state_dict()[k]), k
+        a["model"].eval(), b["model"].eval()
+        assert torch.equal(a["model"].full_sort_topk(a["batch"], 20), b["model"].full_sort_topk(b["batch"], 20))
+

@@ -1203,3 +1203,56 @@ def test_whole_run_on_device_follows_reference(tmp_path, golden, run):
     slack = 0.03          # a few near-tie ranks among 200 users
     np.testing.assert_allclose(valid, ref["valid"], atol=slack)
     np.testing.assert_allclose(test, ref["test"], atol=slack)
+
+
+@pytest.mark.parametrize("how", ["degree", "rcm", "community"])
+def test_freedom_relabelled_id_space_is_bitwise_the_plain_model(tmp_path, golden, how):
+    """config `reorder` on the device: FREEDOM with its tables in a relabelled id space (models/_base.py: RelabelledIdsMixin)
+    against the plain plugin -- the relabelled graphs keep every row's nonzero order, so the propagated tables, the loss and
+    (in `hip_deterministic` mode: position-ordered scatters) every gradient are the plain model's BIT FOR BIT after
+    un-permuting; full-sort top-K lists identical in the dataset's ids; the default (atomic) backward within rounding."""
+    from mmrec_amd import hip_ops
+    if not USE_GPU:
+        pytest.skip("the CPU twin is tests/test_models_cpu.py::test_freedom_relabelled_id_space_is_the_same_model")
+    out = {}
+    try:
+        for det in (True, False):
+            for key in (None, how):
+                extra = {"dropout": 0.8, "reg_weight": 1e-3, "hip_deterministic": det, "hip_graph_step": False}
+                if key:
+                    extra["reorder"] = key
+                config, train_data, valid_data, model = build(tmp_path / ("d%d%s" % (det, key)), golden, "FREEDOM", extra)
+                hip_ops.set_deterministic(det)
+                model.set_kept_edges(torch.as_tensor(golden["fr_keep_idx"]).to(model.device))
+                loss = model.calculate_loss(batch_of(golden, model.device))
+                loss.backward()
+                rl = model.relabelling
+                grads = {}
+                for n, p in model.named_parameters():
+                    if p.grad is not None:
+                        side = model.relabelled_tables.get(n)
+                        grads[n] = (p.grad.index_select(0, rl.perm_u if side == "u" else rl.perm_i) if (rl is not None and side)
+                                    else p.grad).clone()
+                model.eval()
+                u, i = model.eval_embeddings()
+                if rl is not None:
+                    u, i = u.index_select(0, rl.perm_u), i.index_select(0, rl.perm_i)
+                batch = next(iter(valid_data))
+                out[(det, key)] = (loss.detach().clone(), grads, u.clone(), i.clone(), model.full_sort_topk(batch, 20).clone(),
+                                   {k: v.clone() for k, v in model.state_dict().items()})
+    finally:
+        hip_ops.set_deterministic(False)
+    for det in (True, False):
+        a, b = out[(det, None)], out[(det, how)]
+        assert torch.equal(a[0], b[0]), (det, float(a[0]), float(b[0]))
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])              # evaluation tables, bit for bit
+        assert torch.equal(a[4], b[4])
+        for k in a[5]:
+            assert torch.equal(a[5][k], b[5][k]), k                              # state_dict in the original row order
+        assert set(a[1]) == set(b[1])
+        for n in a[1]:
+            if det:
+                assert torch.equal(a[1][n], b[1][n]), n
+            else:
+                torch.testing.assert_close(b[1][n], a[1][n], rtol=1e-5, atol=1e-9, msg=n)
+

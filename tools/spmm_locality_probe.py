@@ -88,6 +88,22 @@ def measure(dev, log=print):
                 log("%-28s d64 %.3f ms  d8 %.3f ms per layer; permute in + out %.3f ms per propagation; relabelling %.1f s on the host"
                     % ("scrambled + " + how, rec["ms_per_layer_d64"], rec["ms_per_layer_d8"], rec["ms_two_permutation_passes_d64"], host_s))
                 del pg
+            # what the plugins do with config `reorder` (models/_base.py: RelabelledIdsMixin): users ranked among users, items
+            # among items (two tables stay two tables), every table KEPT in the relabelled space -- the layer time below is
+            # the whole cost, there are no permutation passes
+            from mmrec_amd.graph import BipartiteRelabelling, relabel_graph
+            t0 = time.time()
+            rl = BipartiteRelabelling(g, nu, ni, "community", dev)
+            gm = relabel_graph(g, rl.node_perm_host())
+            host_s = time.time() - t0
+            rec = {"ms_per_layer_d%d" % d: time_layer(gm, x[d], y[d]) for d in x}
+            rec["ms_two_permutation_passes_d64"] = 0.0
+            rec["relabel_host_s"] = host_s
+            rec["what"] = "config `reorder: community` as FREEDOM applies it: tables live in the relabelled ids, nothing is permuted per step"
+            out["scrambled+community_in_model"] = rec
+            log("%-28s d64 %.3f ms  d8 %.3f ms per layer; no permutation passes; relabelling %.1f s on the host"
+                % ("scrambled + reorder (model)", rec["ms_per_layer_d64"], rec["ms_per_layer_d8"], host_s))
+            del gm
         del g
     return out
 
