@@ -423,9 +423,10 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ X,
                                                            float* __restrict__ part,
                                                            float* __restrict__ dbpart, int n, int F,
-                                                           int n_chunk, int ldg) {
+                                                           int n_chunk, int ldg, const int* __restrict__ redo = nullptr) {
     __shared__ __attribute__((aligned(16))) float Gs[BW_BK][64];
     __shared__ __attribute__((aligned(16))) float Xs[BW_BK][BW_BF];
+    if (redo && !redo[blockIdx.x]) return;      // fix-up launch of mmrec_linear_bwd_split_f32: flagged 128-column blocks only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * BW_BF;
     const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
@@ -626,6 +627,364 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restri
         }
     }
 }
+
+// =====================================================================================================================
+// Projection BACKWARD on the 16-bit matrix cores with split operands (ABI 11: mmrec_linear_bwd_split_f32).
+// dW = dY^T X and dX = dY W are fp32-MFMA bound in the kernels above (2 n F 64 FLOP each at the 1/16-rate fp32 matrix pipe:
+// 23.5 us at Amazon-Baby size at the nominal clock, 40 us measured) although each only has to stream X once (dW) or write dX once.
+// Same split as the forward (x = hi + 2^-11 lo' in fp16, three fp16 products, fp32 accumulators, error <= 2^-21 |a b| per
+// product), with the operands brought into fp16's range by exact power-of-two scales that are undone in the epilogue:
+//   * dY (gradients: 1e-3 ... 1e-12) -- dW: one scale per OUTPUT COLUMN o, from the column maxima of dY (bwd_dy_colmax_kernel),
+//     applied when dY is written transposed + split into the tile layout the MFMA's A operand wants (bwd_dy_tsplit_kernel, which
+//     also produces the bias gradient's partial sums in fp32); dX: one scale per ROW of dY, in registers (K = 64: a lane pair
+//     holds the whole row);
+//   * W -- dX: one scale per COLUMN f (the 64 weights of one feature), applied when W is written transposed + split
+//     (bwd_wt_split_kernel);
+//   * X -- dW: unscaled, like the forward, and with the forward's guard: a 128-column block with a non-finite result or a column
+//     whose largest |x| is below 2^-10 (not 0) is recomputed by the fp32 kernel (redo flags, no host synchronisation).
+// Inf / NaN anywhere give inf / NaN results as F.linear's backward does (scales fall back to 1).
+// =====================================================================================================================
+__device__ __forceinline__ void split8(const float (&x)[8], g_half8& hi, g_half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)((x[e] - (float)h) * 2048.f);
+    }
+}
+// exact power-of-two scale that brings a maximum magnitude `mx` into [2^target, 2^(target + 1)), and its inverse; 1 for
+// mx == 0 and for inf / NaN (which then propagate); clamped for maxima below 2^-100
+__device__ __forceinline__ void pow2_scale(float mx, int target, float& sc, float& inv) {
+    const unsigned bits = __float_as_uint(mx) & 0x7fffffffu;
+    const int ex = (int)(bits >> 23);
+    if (bits == 0u || ex == 255) { sc = 1.f; inv = 1.f; return; }
+    int e = target + 127 - ex;                       // sc = 2^e
+    e = max(-120, min(120, e));
+    sc = __uint_as_float((unsigned)(e + 127) << 23);
+    inv = __uint_as_float((unsigned)(127 - e) << 23);
+}
+
+// W [64][F] -> Wt_sp: row f = 256 B = 16 chunks of 16 B: chunks 0..7 the fp16 hi halves of cs_f w[8c .. 8c + 7][f], chunks 8..15
+// the lo' halves; chunk c is stored at position c ^ (f & 15) (the LDS-DMA copies a 128-row tile linearly; the swizzle makes the
+// 16-B fragment reads of 32 consecutive rows conflict free).  wcs_inv[f] = 1 / cs_f.  Block 0 also clears the cells K1 raises
+// (dY column maxima) and the redo flags of the dW guard.
+__global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wt_sp,
+                                                           float* __restrict__ wcs_inv, unsigned* __restrict__ cells,
+                                                           int* __restrict__ redo, int n_redo) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 64) cells[threadIdx.x] = 0u;
+        for (int j = threadIdx.x; j < n_redo; j += 256) redo[j] = 0;
+    }
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float w[64], mx = 0.f;
+#pragma unroll
+    for (int o = 0; o < 64; ++o) {
+        w[o] = W[(size_t)o * F + f];
+        mx = fmaxf(mx, fabsf(w[o]));       // (NaN: fmaxf drops it; the products below still carry it)
+    }
+    float cs, inv;
+    pow2_scale(mx, 0, cs, inv);
+    wcs_inv[f] = inv;
+    float* row = Wt_sp + (size_t)f * 64;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w[8 * c + e] * cs;
+        g_half8 hi, lo;
+        split8(x, hi, lo);
+        *reinterpret_cast<g_half8*>(row + ((c ^ (f & 15)) << 2)) = hi;
+        *reinterpret_cast<g_half8*>(row + (((8 + c) ^ (f & 15)) << 2)) = lo;
+    }
+}
+
+// cells[o] = max_i |dY[i][o]| as the bit pattern of a non-negative float (monotone as unsigned; a NaN's pattern is larger than
+// inf's, so non-finite entries surface as ex == 255 in pow2_scale).  Grid-stride over rows, one atomicMax per column and block.
+__global__ __launch_bounds__(256) void bwd_dy_colmax_kernel(const float* __restrict__ dY, int n, unsigned* __restrict__ cells) {
+    __shared__ unsigned red[16][64];
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    for (int row = blockIdx.x * 16 + r0; row < n; row += gridDim.x * 16) {
+        const float4 v = reinterpret_cast<const float4*>(dY)[(size_t)row * 16 + c4];
+        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu);
+        m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu);
+        m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[r0][4 * c4 + e] = m[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned t = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t = max(t, red[k][threadIdx.x]);
+        if (t) atomicMax(cells + threadIdx.x, t);
+    }
+}
+
+// One workgroup per 32-item block b: dY[32 b .. +31][0..63] -> the 8 KB tile the dW kernel's LDS-DMA copies linearly:
+// row o = 128 B = 8 chunks of 16 B: chunks 0..3 the hi halves of S_o dY[32 b + 8 q .. + 7][o] (q = chunk), chunks 4..7 the lo'
+// halves; chunk c at position c ^ ((o >> 1) & 7) (the forward's W-tile swizzle).  S_o brings column o's maximum to [2^14, 2^15).
+// dbpart[b][o] = sum of the block's 32 items of column o, in fp32, items in order (bias gradient; db_reduce_kernel sums blocks).
+__global__ __launch_bounds__(256) void bwd_dy_tsplit_kernel(const float* __restrict__ dY, int n, const unsigned* __restrict__ cells,
+                                                            float* __restrict__ dYt_sp, float* __restrict__ dbpart) {
+    __shared__ __attribute__((aligned(16))) float Gs[32][64 + 1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int e = tid + 256 * p, r = e >> 4, c = (e & 15) * 4;
+        const int item = 32 * b + r;
+        const float4 v = item < n ? reinterpret_cast<const float4*>(dY)[(size_t)item * 16 + (e & 15)] : f4_zero();
+        Gs[r][c] = v.x; Gs[r][c + 1] = v.y; Gs[r][c + 2] = v.z; Gs[r][c + 3] = v.w;
+    }
+    __syncthreads();
+    const int o = tid >> 2, q = tid & 3;
+    float sc, inv;
+    pow2_scale(__uint_as_float(cells[o]), 14, sc, inv);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = Gs[8 * q + e][o] * sc;
+    g_half8 hi, lo;
+    split8(x, hi, lo);
+    float* row = dYt_sp + (size_t)b * 2048 + o * 32;
+    const int sw = (o >> 1) & 7;
+    *reinterpret_cast<g_half8*>(row + ((q ^ sw) << 2)) = hi;
+    *reinterpret_cast<g_half8*>(row + (((4 + q) ^ sw) << 2)) = lo;
+    if (dbpart && tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += Gs[k][tid];
+        dbpart[(size_t)b * 64 + tid] = t;
+    }
+}
+
+// dW partial[o][f] over an item chunk on v_mfma_f32_32x32x16_f16: D[i = o][j = f], contraction over items.  grid (F / 128, nsplit);
+// wave w owns the 32 columns f0 + 32 w .. and all 64 outputs.  A fragments come ready from the pre-split dY tile (one 16-B LDS
+// read per 8 items), B fragments are 8 lane-consecutive ds_read_b32 of the fp32 X tile, split in registers.  Same 3-stage LDS-DMA
+// ring as linear_bwd_w_dma_kernel (X tile natural [item][f], G tile 8 KB linear).  Needs n_chunk * F * 4 < 2^31.
+__global__ __launch_bounds__(256, 2) void bwd_w_f16x3_kernel(const float* __restrict__ dYt_sp, const float* __restrict__ X,
+                                                             float* __restrict__ part, float* __restrict__ colmax_part,
+                                                             int* __restrict__ redo, const unsigned* __restrict__ cells, int n,
+                                                             int F, int n_chunk) {
+    __shared__ __attribute__((aligned(1024))) float G0[2048], G1[2048], G2[2048];
+    __shared__ __attribute__((aligned(1024))) float X0[BW_BK * BW_BF], X1[BW_BK * BW_BF], X2[BW_BK * BW_BF];
+    __shared__ float s_inv[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = blockIdx.x * BW_BF;
+    const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
+    const int rows = ne - nb;
+    if (tid < 64) {
+        float sc, inv;
+        pow2_scale(__uint_as_float(cells[tid]), 14, sc, inv);
+        s_inv[tid] = inv;
+    }
+    const int T = (rows + BW_BK - 1) / BW_BK;
+    const i32x4 rx = raw_rsrc(X + (size_t)nb * F + f0, (unsigned)rows * (unsigned)F * 4u - (unsigned)f0 * 4u);
+    const i32x4 rg = raw_rsrc(dYt_sp + (size_t)(nb / BW_BK) * 2048, (unsigned)T * 8192u);
+    int vx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vx[j] = (2 * (4 * wave + j) + (lane >> 5)) * F * 4 + (lane & 31) * 16;
+    auto issue = [&](float* gs, float* xs, int t) {
+        const int sx = t * BW_BK * F * 4, sg = t * 8192;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16<false>(rx, lds_addr(xs + (4 * wave + j) * 256), vx[j], sx);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) lds_dma16<false>(rg, lds_addr(gs + (2 * wave + j) * 256), (2 * wave + j) * 1024 + lane * 16, sg);
+    };
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 hh0 = {0}, hh1 = {0}, cx0 = {0}, cx1 = {0};
+    float xmax = 0.f;
+    const int sw0 = (i >> 1) & 7, sw1 = ((32 + i) >> 1) & 7;
+    auto compute = [&](const float* gs, const float* xs) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const g_half8 ah0 = *reinterpret_cast<const g_half8*>(gs + i * 32 + (((2 * st + h) ^ sw0) << 2));
+            const g_half8 al0 = *reinterpret_cast<const g_half8*>(gs + i * 32 + (((4 + 2 * st + h) ^ sw0) << 2));
+            const g_half8 ah1 = *reinterpret_cast<const g_half8*>(gs + (32 + i) * 32 + (((2 * st + h) ^ sw1) << 2));
+            const g_half8 al1 = *reinterpret_cast<const g_half8*>(gs + (32 + i) * 32 + (((4 + 2 * st + h) ^ sw1) << 2));
+            float xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = xs[(16 * st + 8 * h + e) * BW_BF + 32 * wave + i];
+            g_half8 bh, bl;
+            split8(xv, bh, bl);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) xmax = fmaxf(fmaxf(xmax, fabsf(xv[e])), fabsf(xv[e + 1]));
+            hh0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, hh0, 0, 0, 0);
+            hh1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, hh1, 0, 0, 0);
+            cx0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, cx0, 0, 0, 0);
+            cx1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, cx1, 0, 0, 0);
+            cx0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh, cx0, 0, 0, 0);
+            cx1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, cx1, 0, 0, 0);
+        }
+    };
+    auto step = [&](const float* gc, const float* xc, float* gn, float* xn, int t) {
+        if (t + 1 < T) MMREC_WAIT_VM(6); else MMREC_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < T) issue(gn, xn, t + 2);
+        compute(gc, xc);
+    };
+    if (T > 0) issue(G0, X0, 0);
+    if (T > 1) issue(G1, X1, 1);
+    for (int t = 0; t < T;) {
+        step(G0, X0, G2, X2, t); if (++t >= T) break;
+        step(G1, X1, G0, X0, t); if (++t >= T) break;
+        step(G2, X2, G1, X1, t); ++t;
+    }
+    __syncthreads();                                   // s_inv (T == 0: nothing else has synchronised yet)
+    float* dst = part + (size_t)blockIdx.y * 64 * F;
+    const int f = f0 + wave * 32 + i;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = d_row(r, lane);
+        const float y0 = fmaf(cx0[r], 1.f / 2048.f, hh0[r]) * s_inv[o], y1 = fmaf(cx1[r], 1.f / 2048.f, hh1[r]) * s_inv[32 + o];
+        dst[(size_t)o * F + f] = y0;
+        dst[(size_t)(32 + o) * F + f] = y1;
+        bad |= !(fabsf(y0) < __builtin_inff()) | !(fabsf(y1) < __builtin_inff());
+    }
+    xmax = fmaxf(xmax, __shfl_xor(xmax, 32));           // the two lane halves hold the two item halves of column f
+    if (gridDim.y == 1) bad |= xmax > 0.f && xmax < SPLIT_ROW_MIN;
+    else if (h == 0) colmax_part[(size_t)blockIdx.y * F + f] = xmax;
+    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) redo[blockIdx.x] = 1;
+}
+
+// dW[o][f] = sum_s part[s][o][f] in slab order (four chains, fixed combination: deterministic) + the guard's decision for the
+// split-over-items case: non-finite sums, columns whose |x| maximum over all slabs is tiny -> redo[f / 128]
+__global__ __launch_bounds__(256) void bwd_w_reduce_kernel(const float* __restrict__ part, int nslab, int F,
+                                                           const float* __restrict__ colmax_part, float* __restrict__ dW,
+                                                           int* __restrict__ redo) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x, slab = (size_t)64 * F;
+    if (i4 * 4 >= slab) return;
+    float4 t0 = f4_zero(), t1 = f4_zero(), t2 = f4_zero(), t3 = f4_zero();
+    int s = 0;
+    for (; s + 3 < nslab; s += 4) {
+        t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)(s + 0) * slab)[i4]);
+        t1 = f4_add(t1, reinterpret_cast<const float4*>(part + (size_t)(s + 1) * slab)[i4]);
+        t2 = f4_add(t2, reinterpret_cast<const float4*>(part + (size_t)(s + 2) * slab)[i4]);
+        t3 = f4_add(t3, reinterpret_cast<const float4*>(part + (size_t)(s + 3) * slab)[i4]);
+    }
+    for (; s < nslab; ++s) t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)s * slab)[i4]);
+    const float4 t = f4_add(f4_add(t0, t1), f4_add(t2, t3));
+    reinterpret_cast<float4*>(dW)[i4] = t;
+    const float inf = __builtin_inff();
+    bool bad = !(fabsf(t.x) < inf) | !(fabsf(t.y) < inf) | !(fabsf(t.z) < inf) | !(fabsf(t.w) < inf);
+    const int f = (int)((i4 * 4) % (size_t)F);
+    if (i4 * 4 < (size_t)F) {                           // the threads of row o = 0 look at their four columns' maxima
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float mx = 0.f;
+            for (int q = 0; q < nslab; ++q) mx = fmaxf(mx, colmax_part[(size_t)q * F + f + e]);
+            bad |= mx > 0.f && mx < SPLIT_ROW_MIN;
+        }
+    }
+    if (bad) redo[f / BW_BF] = 1;
+}
+
+// dX[n, F] = dY[n, 64] W[64, F] on v_mfma_f32_32x32x16_f16, the streaming form of gemm64_stream_kernel (mfma_stream.h): a
+// workgroup owns 128 rows and walks `ftiles` 128-column tiles; waves 0-3 keep their 32 x 64 dY fragment -- scaled per row,
+// split -- in registers for the whole walk and issue LDS reads, 12 MFMAs and 16 row-segment stores per 32-column sub-tile; wave 4
+// brings the pre-split W^T tiles (32 KB, linear) and their 128 column scales by LDS-DMA into a double buffer and is the only wave
+// that waits on vmcnt.  Output-write bound: n F 4 bytes.
+__global__ __launch_bounds__(320, 2) void bwd_x_f16x3_kernel(const float* __restrict__ dY, const float* __restrict__ Wt_sp,
+                                                             const float* __restrict__ wcs_inv, float* __restrict__ dX, int n,
+                                                             int F, int ftiles) {
+    __shared__ __attribute__((aligned(1024))) float Wa[8192 + 256], Wb[8192 + 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 128;
+    const int ft0 = blockIdx.y * ftiles, ftn = min(ftiles, F / 128 - ft0);
+    if (wave == 4) {  // ------------------------------------------------------------ loader wave
+        const i32x4 rw = raw_rsrc(Wt_sp, (unsigned)F * 256u);
+        const i32x4 rs = raw_rsrc(wcs_inv, (unsigned)F * 4u);
+        auto fill = [&](float* ws, int ft) {
+            const int so = (ft0 + ft) * 32768;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) lds_dma16<false>(rw, lds_addr(ws + j * 256), lane * 16, so + j * 1024);
+            lds_dma16<false>(rs, lds_addr(ws + 8192), lane * 16, (ft0 + ft) * 512);     // (lanes 32-63: the next tile's, unused)
+            MMREC_WAIT_VM(0);
+        };
+        if (ftn > 0) fill(Wa, 0);
+        for (int ft = 0; ft < ftn;) {
+            __builtin_amdgcn_s_barrier();            // tile ft landed; the other buffer is drained
+            if (ft + 1 < ftn) fill(Wb, ft + 1);
+            if (++ft >= ftn) break;
+            __builtin_amdgcn_s_barrier();
+            if (ft + 1 < ftn) fill(Wa, ft + 1);
+            ++ft;
+        }
+        return;
+    }
+    const int i = lane & 31, h = lane >> 5;
+    // A fragments: row m0 + 32 wave + i of dY, k = 16 s + 8 h .. + 7 per MFMA step s; rows past n read as zero
+    const int arow = m0 + wave * 32 + i;
+    float a[4][8];
+    float rmax = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const float4 u = ld4_guard(dY + (size_t)arow * 64 + 16 * st + 8 * h, arow < n);
+        const float4 v = ld4_guard(dY + (size_t)arow * 64 + 16 * st + 8 * h + 4, arow < n);
+        a[st][0] = u.x; a[st][1] = u.y; a[st][2] = u.z; a[st][3] = u.w;
+        a[st][4] = v.x; a[st][5] = v.y; a[st][6] = v.z; a[st][7] = v.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {     // (bit patterns: a NaN or inf element must surface in the maximum)
+            const float ax = fabsf(a[st][e]);
+            rmax = __uint_as_float(max(__float_as_uint(rmax), __float_as_uint(ax)));
+        }
+    }
+    rmax = __uint_as_float(max(__float_as_uint(rmax), __float_as_uint(__shfl_xor(rmax, 32))));
+    float rsc, rinv;
+    pow2_scale(rmax, 0, rsc, rinv);
+    g_half8 ah[4], al[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = a[st][e] * rsc;
+        split8(x, ah[st], al[st]);
+    }
+    float rs16[16];     // inverse row scale of the 16 rows this lane's accumulator registers belong to
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs16[r] = __shfl(rinv, d_row(r, lane));
+    const unsigned lane_off = (unsigned)(4 * h * F + i) * 4u;
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dX + (size_t)m0 * F), 0, (unsigned)min(128, n - m0) * (unsigned)F * 4u, 0x00020000);   // rows past n: dropped
+    auto tile = [&](const float* ws, int ft) {
+        const int tcol = ((ft0 + ft) * 128) * 4;  // byte offset of this f tile within a row
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = 32 * t + i, sw = col & 15;
+            const float* wr = ws + col * 64;
+            f32x16 hh = {0}, cx = {0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const g_half8 bh = *reinterpret_cast<const g_half8*>(wr + (((2 * st + h) ^ sw) << 2));
+                const g_half8 bl = *reinterpret_cast<const g_half8*>(wr + (((8 + 2 * st + h) ^ sw) << 2));
+                hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], bh, hh, 0, 0, 0);
+                cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], bl, cx, 0, 0, 0);
+                cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st], bh, cx, 0, 0, 0);
+            }
+            const float cinv = ws[8192 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                const float v = fmaf(cx[r], 1.f / 2048.f, hh[r]) * (rs16[r] * cinv);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdx, (int)lane_off,
+                                                      (wave * 32 + rr) * F * 4 + tcol + t * 128, 0);
+            }
+        }
+    };
+    for (int ft = 0; ft < ftn;) {
+        __builtin_amdgcn_s_barrier();
+        tile(Wa, ft);
+        if (++ft >= ftn) break;
+        __builtin_amdgcn_s_barrier();
+        tile(Wb, ft);
+        ++ft;
+    }
+}
+
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Split of the contraction extent over workgroups.  With `tiles` output tiles and 256 CUs the

@@ -76,6 +76,10 @@ constexpr int F_P1S2_NC = 131072;    // from this many candidates on pass 1 walk
 constexpr int F_WLIST_X = 2;         // a query's list holds F_WLIST_X x as many words as the final kernel has survivor slots: the
                                      // overflow kernel ranks the queries in between (heavy users, closely packed scores, ties)
 constexpr int F_OVER_IDS = 4096;     // survivors of ONE overflowing query the overflow kernel ranks (16 KiB of LDS)
+#ifndef MMREC_TF_FINAL_ROWS
+#define MMREC_TF_FINAL_ROWS 8
+#endif
+constexpr int F_FINAL_ROWS = MMREC_TF_FINAL_ROWS;   // candidate rows in flight per lane in the final kernel's exact rescoring
 constexpr int F_PF = 4;        // 64-candidate stages in flight per workgroup (register ring)
 constexpr int F_MASK_LDS = 512; // mask entries per query staged in LDS by the final kernel (>= F_MAXR * 32)
 
@@ -931,20 +935,22 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (valid < k) bad = true;
         if (!bad) {
-            // C: exact scores, 16 lanes per candidate row, 8 rows in flight per lane
+            // C: exact scores, 16 lanes per candidate row, F_FINAL_ROWS rows in flight per lane (4 x as many per wave and L2
+            // round trip; tools/prof_topk_variants.py `final16`: 16 rows = 2 x fewer round trips, 116 instead of 68 VGPRs)
             const int sub = lane & 15, g = lane >> 4;
-            for (int e0 = 0; e0 < valid; e0 += 32) {
-                int id[8];
-                float4 cv[8][KB];
+            constexpr int NR = F_FINAL_ROWS;
+            for (int e0 = 0; e0 < valid; e0 += 4 * NR) {
+                int id[NR];
+                float4 cv[NR][KB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) id[u] = e0 + 4 * u + g < valid ? s_ids[wave][e0 + 4 * u + g] : -1;
+                for (int u = 0; u < NR; ++u) id[u] = e0 + 4 * u + g < valid ? s_ids[wave][e0 + 4 * u + g] : -1;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < NR; ++u)
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)
                         cv[u][kb] = id[u] >= 0 ? reinterpret_cast<const float4*>(C)[(size_t)id[u] * (16 * KB) + kb * 16 + sub] : f4_zero();
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < NR; ++u) {
                     float part = f4_dot(qv[0], cv[u][0]);
                     if (KB == 2) part += f4_dot(qv[KB - 1], cv[u][KB - 1]);      // chunk + 16: the order of exact_score<2>
                     const float sc = row16_sum(part);

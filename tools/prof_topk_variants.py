@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "probe_libs")
 VARIANTS = {          # name -> defines
     "current": [],                                # the tree as it is (pass 1 on every second stage from 131,072 candidates on)
-    "occ3": ["-DMMREC_TF_OCC3=1"],                # word-list pass 2 (kd = 64) at three workgroups per CU: 166 VGPRs, no spills since the prefetch fix
-    "p1s1": ["-DMMREC_TF_P1S=1", "-DMMREC_TF_NOCLIP=1"],    # pass 1 on every stage everywhere, no clipping (the round-2 behaviour)
+    "final16": ["-DMMREC_TF_FINAL_ROWS=16"],      # final kernel: 16 instead of 8 candidate rows in flight per lane (116 instead of 68 VGPRs)
+    "final12": ["-DMMREC_TF_FINAL_ROWS=12"],
 }
 
 
