@@ -573,6 +573,13 @@ def extra_baby(dev):
     out["baby_linear4096_fwd_bwd_mode"] = st["mode"]
     out["baby_linear4096_fwd_bwd_tflops"] = 3 * 2.0 * ni * 4096 * 64 / st["median"] / 1e12
     out["baby_linear4096_fwd_bwd_us_eager_wall"] = timeit(fwd_bwd, reps=100, warm=10) * 1e6
+    hip_ops.LINEAR_F16X3 = False                           # A/B: forward, dW and dX on the fp32-MFMA kernels
+    Xg.grad = Wg.grad = bg.grad = None
+    st32 = graph_timeit(fwd_bwd, reps=100, windows=5, warm=5)
+    hip_ops.LINEAR_F16X3 = True
+    out["baby_linear4096_fwd_bwd_us_fp32_mfma_kernels"] = st32["median"] * 1e6
+    # the backward's write roofline: dX is n x 4096 fp32 written once (kernel time from the in-run counters pass below)
+    out["projection_roofline"]["baby"]["dx_bytes_written"] = 4.0 * ni * 4096
     Xg.grad = Wg.grad = bg.grad = None
     for key, lazy in (("baby_freedom_train_step", False), ("baby_freedom_train_step_lazy", True)):
         reps, windows, warm = 20, 5, 3
@@ -700,7 +707,7 @@ def measure_mfma(n_items):
         per = {}          # kernel -> dispatch -> counter -> value (a dispatch has one row per counter and XCD: summed)
         for row in csv.DictReader(open(files[0])):
             k = row["Kernel_Name"]
-            if "linear_" not in k and "slab_reduce" not in k:
+            if "linear_" not in k and "slab_reduce" not in k and "f16x3" not in k and "gemm64_stream" not in k:
                 continue
             short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
             cs = per.setdefault(short, {}).setdefault(row.get("Dispatch_Id", ""), {})
@@ -709,7 +716,7 @@ def measure_mfma(n_items):
         for tf in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for row in csv.DictReader(open(tf)):
                 k = row["Kernel_Name"]
-                if "linear_" in k or "slab_reduce" in k:
+                if "linear_" in k or "slab_reduce" in k or "f16x3" in k or "gemm64_stream" in k:
                     short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
                     dur.setdefault(short, []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
         out = {}
@@ -1373,6 +1380,12 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                 got = None if (args.no_pmc or not n_proj) else measure_mfma(n_proj)
                 if got:
                     pr["mfma_util_counters"] = got
+                    for kname, rec in got.items():     # dX: n x 4096 fp32 written once -> fraction of the 8 TB/s (write) roofline
+                        if kname.startswith(("bwd_x_f16x3", "gemm64_stream")) and rec.get("duration_us"):
+                            rec["write_gbs"] = 4.0 * n_proj * 4096 / (rec["duration_us"] * 1e-6) / 1e9
+                            rec["frac_write_roofline"] = rec["write_gbs"] / HBM_PEAK_GBS
+                        if kname.startswith(("bwd_w_f16x3", "linear_bwd_w_dma", "linear_fwd_dma")) and rec.get("duration_us"):
+                            rec["x_stream_gbs"] = 4.0 * n_proj * 4096 / (rec["duration_us"] * 1e-6) / 1e9
                     pr["counters_source"] = ("in-run: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES, one "
                                              "pass, 4 forward + backward calls at %d items; MfmaUtil_busy_cu = MFMA busy cycles / "
                                              "(4 SIMDs x busy CU cycles)" % n_proj)

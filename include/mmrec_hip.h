@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 10
+#define MMREC_ABI_VERSION 11
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -208,11 +208,25 @@ int mmrec_linear_fwd_f32(const float* X, const float* W, const float* b, float* 
                          int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 /* ABI 8 -- the same projection on the 16-bit matrix cores with SPLIT operands: x = hi + 2^-11 lo' in fp16, three fp16 MFMA
  * products per 16 k instead of eight fp32 ones (fp32-input MFMA is 1/16 of the 16-bit rate and bounds the fp32 form), fp32
- * accumulators, error <= 2^-21 |x||w| per term -- as accurate against float64 as the fp32 form.  Domain |x|, |w| < 32768.
- * Arguments, workspace (mmrec_linear_workspace_bytes) and results (to rounding) as mmrec_linear_fwd_f32; F % 32 != 0 is served
- * by it. */
+ * accumulators, error <= 2^-21 |x||w| per term -- as accurate against float64 as the fp32 form.
+ * The whole fp32 range is served (round 5): rows of X / W outside what fp16 can hold -- |.| >= 65520, inf, NaN (found as a
+ * non-finite result), or a row whose largest magnitude is below 2^-10 and not 0 -- are detected ON THE DEVICE and their
+ * 128-row blocks recomputed by the fp32 kernel inside the same call (flags in the workspace, a second launch that returns at
+ * once for unflagged blocks; no host synchronisation, capture-safe).  Unflagged rows: |err| <= 2^-21 sum |x w| + 2^-25 max|x_row|
+ * sum |w_row|.  Arguments, workspace (mmrec_linear_workspace_bytes) and results (to rounding) as mmrec_linear_fwd_f32;
+ * F % 32 != 0 is served by it. */
 int mmrec_linear_fwd_split_f32(const float* X, const float* W, const float* b, float* Y, int32_t n, int32_t F,
                                int32_t out, void* workspace, mmrec_stream_t stream);
+/* ABI 11 -- the projection's BACKWARD with split operands, one call: dW [64, F] = dY^T X, db [64] = column sums of dY (fp32,
+ * fixed order), dX [n, F] = dY W  (autograd of nn.Linear: freedom.py:58-62,205,208; bm3.py:51-56; lattice.py:90-92).  dW (with
+ * db or without) and dX may each be NULL (not wanted).  The operands are brought into fp16's range by exact power-of-two
+ * scales (per column of dY for dW, per row of dY and per column of W for dX), X is taken as it is with the forward's guard
+ * per 128-column block (fp32 fix-up on the device); inf / NaN propagate.  out == 64 and F % 128 == 0 run these kernels, every
+ * other shape is handed to mmrec_linear_bwd_w_f32 / mmrec_linear_bwd_x_f32.  Deterministic (no float atomics).
+ * workspace: mmrec_linear_bwd_split_workspace_bytes (>= mmrec_linear_workspace_bytes). */
+size_t mmrec_linear_bwd_split_workspace_bytes(int32_t n, int32_t F, int32_t out);
+int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const float* W, float* dW, float* db, float* dX, int32_t n,
+                               int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW, float* db, int32_t n,
                            int32_t F, int32_t out, void* workspace, mmrec_stream_t stream);
 int mmrec_linear_bwd_x_f32(const float* dY, const float* W, float* dX, int32_t n, int32_t F,

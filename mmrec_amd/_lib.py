@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MMREC_HIP_LIB: load another build of the same library (kernel A/B measurements: tools/prof_topk_filter.py)
 LIB_PATH = os.environ.get("MMREC_HIP_LIB") or os.path.join(_PKG, "lib", "libmmrec_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _P = c_void_p  # every device/host pointer travels as void*
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "mmrec_linear_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mmrec_linear_fwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "mmrec_linear_fwd_split_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "mmrec_linear_bwd_split_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "mmrec_linear_bwd_split_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "mmrec_linear_bwd_w_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "mmrec_linear_bwd_x_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "mmrec_gemm_nt_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),

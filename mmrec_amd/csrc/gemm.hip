@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ X,
                                                            float* __restrict__ part,
                                                            float* __restrict__ dbpart, int n, int F,
-                                                           int n_chunk, int ldg, const int* __restrict__ redo = nullptr) {
+                                                           int n_chunk, int ldg, const int* __restrict__ redo) {
     __shared__ __attribute__((aligned(16))) float Gs[BW_BK][64];
     __shared__ __attribute__((aligned(16))) float Xs[BW_BK][BW_BF];
     if (redo && !redo[blockIdx.x]) return;      // fix-up launch of mmrec_linear_bwd_split_f32: flagged 128-column blocks only
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_w_dma_kernel(const float* _
                                                                   const float* __restrict__ X,
                                                                   float* __restrict__ part,
                                                                   float* __restrict__ dbpart, int n, int F,
-                                                                  int n_chunk, int ldg) {
+                                                                  int n_chunk, int ldg, const int* __restrict__ /*redo: unused*/) {
     __shared__ __attribute__((aligned(1024))) float G0[BW_BK * 64], G1[BW_BK * 64], G2[BW_BK * 64];
     __shared__ __attribute__((aligned(1024))) float X0[BW_BK * BW_BF], X1[BW_BK * BW_BF], X2[BW_BK * BW_BF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void bwd_dy_colmax_kernel(const float* __restr
     __shared__ unsigned red[16][64];
     const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
     unsigned m[4] = {0u, 0u, 0u, 0u};
-    for (int row = blockIdx.x * 16 + r0; row < n; row += gridDim.x * 16) {
+    for (int row = blockIdx.x * 16 + r0; row < n; row += gridDim.x * 16) {       // (grid: <= 128 workgroups, see the launch)
         const float4 v = reinterpret_cast<const float4*>(dY)[(size_t)row * 16 + c4];
         m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu);
         m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
@@ -723,40 +723,45 @@ __global__ __launch_bounds__(256) void bwd_dy_colmax_kernel(const float* __restr
     }
 }
 
-// One workgroup per 32-item block b: dY[32 b .. +31][0..63] -> the 8 KB tile the dW kernel's LDS-DMA copies linearly:
-// row o = 128 B = 8 chunks of 16 B: chunks 0..3 the hi halves of S_o dY[32 b + 8 q .. + 7][o] (q = chunk), chunks 4..7 the lo'
-// halves; chunk c at position c ^ ((o >> 1) & 7) (the forward's W-tile swizzle).  S_o brings column o's maximum to [2^14, 2^15).
-// dbpart[b][o] = sum of the block's 32 items of column o, in fp32, items in order (bias gradient; db_reduce_kernel sums blocks).
+// One workgroup per BWD_TB consecutive 32-item blocks (2 ... 64: at most ~1024 workgroups and db partials); per block b: dY[32 b .. +31][0..63] -> the 8 KB tile the dW kernel's
+// LDS-DMA copies linearly: row o = 128 B = 8 chunks of 16 B: chunks 0..3 the hi halves of S_o dY[32 b + 8 q .. + 7][o]
+// (q = chunk), chunks 4..7 the lo' halves; chunk c at position c ^ ((o >> 1) & 7) (the forward's W-tile swizzle).  S_o brings
+// column o's maximum to [2^14, 2^15).  dbpart[workgroup][o] = sum of the workgroup's items of column o, in fp32, items in order
+// (bias gradient; db_reduce_kernel sums the workgroups' partials in order).
 __global__ __launch_bounds__(256) void bwd_dy_tsplit_kernel(const float* __restrict__ dY, int n, const unsigned* __restrict__ cells,
-                                                            float* __restrict__ dYt_sp, float* __restrict__ dbpart) {
+                                                            float* __restrict__ dYt_sp, float* __restrict__ dbpart, int nblk,
+                                                            int BWD_TB) {
     __shared__ __attribute__((aligned(16))) float Gs[32][64 + 1];
-    const int b = blockIdx.x, tid = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int e = tid + 256 * p, r = e >> 4, c = (e & 15) * 4;
-        const int item = 32 * b + r;
-        const float4 v = item < n ? reinterpret_cast<const float4*>(dY)[(size_t)item * 16 + (e & 15)] : f4_zero();
-        Gs[r][c] = v.x; Gs[r][c + 1] = v.y; Gs[r][c + 2] = v.z; Gs[r][c + 3] = v.w;
-    }
-    __syncthreads();
+    const int tid = threadIdx.x;
     const int o = tid >> 2, q = tid & 3;
     float sc, inv;
     pow2_scale(__uint_as_float(cells[o]), 14, sc, inv);
-    float x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = Gs[8 * q + e][o] * sc;
-    g_half8 hi, lo;
-    split8(x, hi, lo);
-    float* row = dYt_sp + (size_t)b * 2048 + o * 32;
     const int sw = (o >> 1) & 7;
-    *reinterpret_cast<g_half8*>(row + ((q ^ sw) << 2)) = hi;
-    *reinterpret_cast<g_half8*>(row + (((4 + q) ^ sw) << 2)) = lo;
-    if (dbpart && tid < 64) {
-        float t = 0.f;
+    float dbacc = 0.f;
+    for (int b = blockIdx.x * BWD_TB; b < min(nblk, (blockIdx.x + 1) * BWD_TB); ++b) {
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 32; ++k) t += Gs[k][tid];
-        dbpart[(size_t)b * 64 + tid] = t;
+        for (int p = 0; p < 2; ++p) {
+            const int e = tid + 256 * p, r = e >> 4, c = (e & 15) * 4;
+            const int item = 32 * b + r;
+            const float4 v = item < n ? reinterpret_cast<const float4*>(dY)[(size_t)item * 16 + (e & 15)] : f4_zero();
+            Gs[r][c] = v.x; Gs[r][c + 1] = v.y; Gs[r][c + 2] = v.z; Gs[r][c + 3] = v.w;
+        }
+        __syncthreads();
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = Gs[8 * q + e][o] * sc;
+        g_half8 hi, lo;
+        split8(x, hi, lo);
+        float* row = dYt_sp + (size_t)b * 2048 + o * 32;
+        *reinterpret_cast<g_half8*>(row + ((q ^ sw) << 2)) = hi;
+        *reinterpret_cast<g_half8*>(row + (((4 + q) ^ sw) << 2)) = lo;
+        if (dbpart && tid < 64) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) dbacc += Gs[k][tid];
+        }
     }
+    if (dbpart && tid < 64) dbpart[(size_t)blockIdx.x * 64 + tid] = dbacc;
 }
 
 // dW partial[o][f] over an item chunk on v_mfma_f32_32x32x16_f16: D[i = o][j = f], contraction over items.  grid (F / 128, nsplit);
@@ -764,9 +769,8 @@ __global__ __launch_bounds__(256) void bwd_dy_tsplit_kernel(const float* __restr
 // read per 8 items), B fragments are 8 lane-consecutive ds_read_b32 of the fp32 X tile, split in registers.  Same 3-stage LDS-DMA
 // ring as linear_bwd_w_dma_kernel (X tile natural [item][f], G tile 8 KB linear).  Needs n_chunk * F * 4 < 2^31.
 __global__ __launch_bounds__(256, 2) void bwd_w_f16x3_kernel(const float* __restrict__ dYt_sp, const float* __restrict__ X,
-                                                             float* __restrict__ part, float* __restrict__ colmax_part,
-                                                             int* __restrict__ redo, const unsigned* __restrict__ cells, int n,
-                                                             int F, int n_chunk) {
+                                                             float* __restrict__ part, int* __restrict__ redo,
+                                                             const unsigned* __restrict__ cells, int n, int F, int n_chunk) {
     __shared__ __attribute__((aligned(1024))) float G0[2048], G1[2048], G2[2048];
     __shared__ __attribute__((aligned(1024))) float X0[BW_BK * BW_BF], X1[BW_BK * BW_BF], X2[BW_BK * BW_BF];
     __shared__ float s_inv[64];
@@ -844,16 +848,16 @@ __global__ __launch_bounds__(256, 2) void bwd_w_f16x3_kernel(const float* __rest
         dst[(size_t)(32 + o) * F + f] = y1;
         bad |= !(fabsf(y0) < __builtin_inff()) | !(fabsf(y1) < __builtin_inff());
     }
-    xmax = fmaxf(xmax, __shfl_xor(xmax, 32));           // the two lane halves hold the two item halves of column f
-    if (gridDim.y == 1) bad |= xmax > 0.f && xmax < SPLIT_ROW_MIN;
-    else if (h == 0) colmax_part[(size_t)blockIdx.y * F + f] = xmax;
+    // the two lane halves hold the two item halves of column f.  The guard is taken per ITEM CHUNK (conservative: a column that
+    // is tiny, and not zero, throughout one workgroup's items is recomputed in fp32 even if other chunks hold ordinary values)
+    xmax = fmaxf(xmax, __shfl_xor(xmax, 32));
+    bad |= xmax > 0.f && xmax < SPLIT_ROW_MIN;
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) redo[blockIdx.x] = 1;
 }
 
-// dW[o][f] = sum_s part[s][o][f] in slab order (four chains, fixed combination: deterministic) + the guard's decision for the
-// split-over-items case: non-finite sums, columns whose |x| maximum over all slabs is tiny -> redo[f / 128]
-__global__ __launch_bounds__(256) void bwd_w_reduce_kernel(const float* __restrict__ part, int nslab, int F,
-                                                           const float* __restrict__ colmax_part, float* __restrict__ dW,
+// dW[o][f] = sum_s part[s][o][f] in slab order (four chains, fixed combination: deterministic); a non-finite sum flags its
+// 128-column block for the fp32 fix-up
+__global__ __launch_bounds__(256) void bwd_w_reduce_kernel(const float* __restrict__ part, int nslab, int F, float* __restrict__ dW,
                                                            int* __restrict__ redo) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x, slab = (size_t)64 * F;
     if (i4 * 4 >= slab) return;
@@ -869,17 +873,8 @@ __global__ __launch_bounds__(256) void bwd_w_reduce_kernel(const float* __restri
     const float4 t = f4_add(f4_add(t0, t1), f4_add(t2, t3));
     reinterpret_cast<float4*>(dW)[i4] = t;
     const float inf = __builtin_inff();
-    bool bad = !(fabsf(t.x) < inf) | !(fabsf(t.y) < inf) | !(fabsf(t.z) < inf) | !(fabsf(t.w) < inf);
-    const int f = (int)((i4 * 4) % (size_t)F);
-    if (i4 * 4 < (size_t)F) {                           // the threads of row o = 0 look at their four columns' maxima
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float mx = 0.f;
-            for (int q = 0; q < nslab; ++q) mx = fmaxf(mx, colmax_part[(size_t)q * F + f + e]);
-            bad |= mx > 0.f && mx < SPLIT_ROW_MIN;
-        }
-    }
-    if (bad) redo[f / BW_BF] = 1;
+    if (!(fabsf(t.x) < inf) | !(fabsf(t.y) < inf) | !(fabsf(t.z) < inf) | !(fabsf(t.w) < inf))
+        redo[(int)((i4 * 4) % (size_t)F) / BW_BF] = 1;
 }
 
 // dX[n, F] = dY[n, 64] W[64, F] on v_mfma_f32_32x32x16_f16, the streaming form of gemm64_stream_kernel (mfma_stream.h): a
@@ -1103,6 +1098,108 @@ extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const 
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
+// ---- ABI 11: the projection's backward on the 16-bit matrix cores (see the kernels' comment block) ----------------------------
+// Workspace layout (mmrec_linear_bwd_split_workspace_bytes): [W^T split: F x 256 B][wcs_inv: F + 256 floats][cells: 64 u32]
+// [redo: F / 128 + 1 ints][dY^T split tiles: ceil(n / 32) x 8 KB][db partials: <= 1024 x 64 floats][dW slabs: nsplit > 1 ?
+// nsplit x 64 x F floats]; never smaller than what the fp32 entry points need (shapes they serve).
+namespace {
+struct BwdSplitWs {
+    size_t wt, wcs, cells, redo, dyt, dbp, slabs, total;
+    int nsplit, chunk, nblk, ndb, tb;
+};
+inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+inline BwdSplitWs bwd_split_ws(int n, int F) {
+    BwdSplitWs w;
+    pick_split(ceil_div(F, BW_BF), n, BW_BK, &w.nsplit, &w.chunk);
+    // LDS-DMA scalar offsets of the dW kernel: a workgroup's item chunk must stay below 2^31 bytes of X
+    while ((size_t)w.chunk * F * 4 >= ((size_t)1 << 31)) {
+        w.chunk = ceil_div(w.chunk / 2, BW_BK) * BW_BK;
+        w.nsplit = ceil_div(n, w.chunk);
+    }
+    w.nblk = ceil_div(n, BW_BK);
+    size_t off = 0;
+    w.wt = off; off += al256((size_t)F * 256);
+    w.wcs = off; off += al256(((size_t)F + 256) * 4);
+    w.cells = off; off += 256;
+    w.redo = off; off += al256(((size_t)F / BW_BF + 1) * 4);
+    w.dyt = off; off += al256((size_t)w.nblk * 8192);
+    w.tb = w.nblk / 512;
+    if (w.tb < 2) w.tb = 2;
+    if (w.tb > 64) w.tb = 64;
+    w.ndb = ceil_div(w.nblk, w.tb);
+    w.dbp = off; off += al256((size_t)w.ndb * 64 * 4);
+    w.slabs = off; off += al256(w.nsplit > 1 ? (size_t)w.nsplit * 64 * F * 4 : 0);
+    w.total = off;
+    return w;
+}
+inline bool bwd_split_serves(int n, int F, int out) { return out == 64 && n > 0 && F > 0 && (F % BW_BF) == 0; }
+}  // namespace
+
+extern "C" size_t mmrec_linear_bwd_split_workspace_bytes(int32_t n, int32_t F, int32_t out) {
+    const size_t plain = mmrec_linear_workspace_bytes(n, F, out);
+    if (!bwd_split_serves(n, F, out)) return plain;
+    const size_t mine = bwd_split_ws(n, F).total;
+    return mine > plain ? mine : plain;
+}
+
+// dW [64, F] = dY^T X, db [64] = column sums of dY, dX [n, F] = dY W in ONE call (any of dW+db / dX may be NULL: not wanted).
+// out == 64 and F % 128 == 0 run the split-operand kernels; other shapes are handed to mmrec_linear_bwd_w_f32 /
+// mmrec_linear_bwd_x_f32 (same workspace).  Results: fp32-accurate (error <= 2^-21 of sum |a b| per output, operands scaled
+// into fp16's range by exact powers of two; X columns outside the split's domain are recomputed in fp32 on the device).
+extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const float* W, float* dW, float* db, float* dX,
+                                          int32_t n, int32_t F, int32_t out, void* workspace, mmrec_stream_t stream) {
+    if (n < 0 || F <= 0 || out <= 0) return MMREC_ERR_BAD_ARG;
+    if (!bwd_split_serves(n, F, out)) {
+        if (dW) {
+            const int rc = mmrec_linear_bwd_w_f32(dY, X, dW, db, n, F, out, workspace, stream);
+            if (rc) return rc;
+        }
+        return dX ? mmrec_linear_bwd_x_f32(dY, W, dX, n, F, out, stream) : 0;
+    }
+    if (!dY || !workspace || (dW && !X) || (dX && !W) || (db && !dW)) return MMREC_ERR_BAD_ARG;
+    hipStream_t s = mmrec_stream(stream);
+    const BwdSplitWs w = bwd_split_ws(n, F);
+    char* base = static_cast<char*>(workspace);
+    float* Wt_sp = reinterpret_cast<float*>(base + w.wt);
+    float* wcs_inv = reinterpret_cast<float*>(base + w.wcs);
+    unsigned* cells = reinterpret_cast<unsigned*>(base + w.cells);
+    int* redo = reinterpret_cast<int*>(base + w.redo);
+    float* dYt = reinterpret_cast<float*>(base + w.dyt);
+    float* dbp = reinterpret_cast<float*>(base + w.dbp);
+    float* slabs = reinterpret_cast<float*>(base + w.slabs);
+    const int ncb = F / BW_BF;
+    // (also clears the cells / redo flags the dW path uses; W may be NULL when only dW is wanted: then the kernel only clears)
+    if (dX)
+        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv, cells, redo, ncb);
+    else
+        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, 0, Wt_sp, wcs_inv, cells, redo, ncb);
+    if (dW) {
+        int cb = ceil_div(n, 64);                // >= 4 rows per thread-row; every workgroup ends with 64 atomicMax on the 64 cells
+        if (cb > 256) cb = 256;
+        hipLaunchKernelGGL(bwd_dy_colmax_kernel, dim3(cb), dim3(256), 0, s, dY, n, cells);
+        hipLaunchKernelGGL(bwd_dy_tsplit_kernel, dim3(w.ndb), dim3(256), 0, s, dY, n, (const unsigned*)cells, dYt,
+                           db ? dbp : (float*)nullptr, w.nblk, w.tb);
+        float* part = w.nsplit == 1 ? dW : slabs;
+        hipLaunchKernelGGL(bwd_w_f16x3_kernel, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
+                           (const unsigned*)cells, n, F, w.chunk);
+        if (w.nsplit > 1)
+            hipLaunchKernelGGL(bwd_w_reduce_kernel, dim3((unsigned)(((size_t)64 * F / 4 + 255) / 256)), dim3(256), 0, s,
+                               (const float*)slabs, w.nsplit, F, dW, redo);
+        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)dbp, w.ndb, db);
+        // fix-up: the fp32 kernel over the flagged 128-column blocks (the others return at once), all items per workgroup
+        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(ncb, 1), dim3(256), 0, s, dY, X, dW, (float*)nullptr, n, F,
+                           ceil_div(n, BW_BK) * BW_BK, 64, (const int*)redo);
+    }
+    if (dX) {
+        const int rt = ceil_div(n, 128), nft = F / 128;
+        int ftiles = 8;
+        while (ftiles > 1 && (long)rt * ceil_div(nft, ftiles) < 192) ftiles >>= 1;
+        hipLaunchKernelGGL(bwd_x_f16x3_kernel, dim3(rt, ceil_div(nft, ftiles)), dim3(320), 0, s, dY, (const float*)Wt_sp,
+                           (const float*)wcs_inv, dX, n, F, ftiles);
+    }
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
 // out = 64 j: the 64-column blocks of dY are handled one after the other (same workspace), each by
 // the out = 64 kernel with dY's row stride = out.
 extern "C" int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW, float* db,
@@ -1132,10 +1229,10 @@ extern "C" int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW
         auto kern = dma ? linear_bwd_w_dma_kernel : linear_bwd_w_kernel;
         if (nsplit == 1) {
             hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), 1), dim3(256), 0, s, g, X, dWz, dbpart, n, F, chunk,
-                               out);
+                               out, (const int*)nullptr);
         } else {
             hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), nsplit), dim3(256), 0, s, g, X, part, dbpart, n, F,
-                               chunk, out);
+                               chunk, out, (const int*)nullptr);
             const size_t elems = (size_t)64 * F;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0,
                                s, part, nsplit, elems, (const float*)nullptr, dWz);

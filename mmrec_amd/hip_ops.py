@@ -990,14 +990,23 @@ class _Linear(torch.autograd.Function):
         n, F = X.shape
         dY = dY.contiguous()
         dX = dW = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+        want_w = ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])
+        if want_w:
             dW = torch.empty_like(W)
             db = torch.empty(64, dtype=torch.float32, device=X.device) if ctx.has_b else None
+        if ctx.needs_input_grad[0]:
+            dX = torch.empty_like(X)
+        if LINEAR_F16X3 and n > 0 and F % 128 == 0:
+            # dW, db and dX in one call on the 16-bit matrix cores with split, power-of-two-scaled operands (ABI 11)
+            ws = _ws(lib.mmrec_linear_bwd_split_workspace_bytes(n, F, 64), X.device)
+            _lib.check(lib.mmrec_linear_bwd_split_f32(_p(dY), _p(X), _p(W), _p(dW), _p(db), _p(dX), n, F, 64, _p(ws),
+                                                      _stream()), "linear_bwd_split")
+            return dX, dW, db
+        if want_w:
             ws = _ws(lib.mmrec_linear_workspace_bytes(n, F, 64), X.device)
             _lib.check(lib.mmrec_linear_bwd_w_f32(_p(dY), _p(X), _p(dW), _p(db), n, F, 64, _p(ws),
                                                   _stream()), "linear_bwd_w")
-        if ctx.needs_input_grad[0]:
-            dX = torch.empty_like(X)
+        if dX is not None:
             _lib.check(lib.mmrec_linear_bwd_x_f32(_p(dY), _p(W), _p(dX), n, F, 64, _stream()),
                        "linear_bwd_x")
         return dX, dW, db

@@ -896,6 +896,114 @@ def test_linear_split_guard_is_capture_safe(ops, dev):
         assert float(((Y.double().cpu() - ref).abs() / sc).max()) <= 1e-6, scale
 
 
+@pytest.mark.parametrize("n,F", [(7050, 4096), (40_000, 4096), (513, 4480), (7050, 384), (2048, 4096)])
+def test_linear_split_backward_is_as_accurate_as_the_fp32_kernels(ops, dev, n, F):
+    """mmrec_linear_bwd_split_f32 (ABI 11; the default backward with hip_ops.LINEAR_F16X3): dW = dY^T X, db, dX = dY W on the 16-bit
+    matrix cores with split, power-of-two-scaled operands, against float64, next to the fp32-MFMA kernels.  Gradients of
+    realistic and of hostile magnitude: rows of dY spread over 1e-2 ... 1e-12 (most rows exactly zero: items outside the batch),
+    one output column of dY 1e-8 of the others, feature weights (columns of W) of 1e-8, a feature (column of X) of 1e-7 and one
+    of 1e5 (both leave the split's domain for X: the guard's fp32 fix-up), errors measured against sum |a b| of each output."""
+    g = torch.Generator().manual_seed(n + F)
+    X = torch.relu(torch.randn(n, F, generator=g))
+    X[:, 5] *= 1e-7
+    X[:, 300] *= 1e5
+    X[:, 301] = 0.0
+    W = torch.randn(64, F, generator=g) / F ** 0.5
+    W[:, 7] *= 1e-8
+    W[:, 200:210] *= 1e4
+    W[:, 333] = 0.0
+    dY = torch.randn(n, 64, generator=g) * 10.0 ** (-2 - 10 * torch.rand(n, 1, generator=g))
+    dY[torch.rand(n, generator=g) < 0.6] = 0.0
+    dY[:, 11] *= 1e-8
+    dY[:, 12] = 0.0
+    Xd, Wd, bd = X.to(dev).requires_grad_(), W.to(dev).requires_grad_(), torch.zeros(64, device=dev, requires_grad=True)
+    out = {}
+    try:
+        for split in (True, False):
+            ops.LINEAR_F16X3 = split
+            Xd.grad = Wd.grad = bd.grad = None
+            ops.linear(Xd, Wd, bd).backward(dY.to(dev))
+            out[split] = (Wd.grad.cpu().double(), bd.grad.cpu().double(), Xd.grad.cpu().double())
+    finally:
+        ops.LINEAR_F16X3 = True
+    dY64, X64, W64 = dY.double(), X.double(), W.double()
+    ref = (dY64.t() @ X64, dY64.sum(0), dY64 @ W64)
+    scale = (dY64.abs().t() @ X64.abs(), dY64.abs().sum(0), dY64.abs() @ W64.abs())
+    for k in (True, False):
+        for j, what in enumerate(("dW", "db", "dX")):
+            err = (out[k][j] - ref[j]).abs() / (scale[j] + 1e-300)
+            err[scale[j] == 0] = (out[k][j] - ref[j]).abs()[scale[j] == 0]
+            # dW's column 300 (|x| ~ 1e5 among ~1: every later addition of an fp32 chain rounds at the large term's ulp)
+            tol = 1e-6 if what != "dW" else 2e-5
+            assert float(err.max()) <= tol, (k, what, float(err.max()))
+            if what == "dW":
+                keep = torch.ones(F, dtype=torch.bool)
+                keep[300] = False
+                assert float(err[:, keep].max()) <= 1e-6, (k, what, float(err[:, keep].max()))
+    assert torch.equal(out[True][0][12], torch.zeros(F, dtype=torch.float64)) and float(out[True][1][12]) == 0.0   # zero gradient column: exact
+    assert torch.equal(out[True][2][dY.abs().sum(1) == 0], torch.zeros(int((dY.abs().sum(1) == 0).sum()), F, dtype=torch.float64))
+
+
+def test_linear_split_backward_nonfinite_and_extremes(ops, dev):
+    """inf / NaN gradients propagate through the split backward as through F.linear's (same pattern of non-finite outputs);
+    gradients of 1e30 and 1e-38 magnitude (scaled by exact powers of two) keep fp32's relative accuracy."""
+    g = torch.Generator().manual_seed(3)
+    n, F = 700, 512
+    X = torch.relu(torch.randn(n, F, generator=g))
+    W = torch.randn(64, F, generator=g) / F ** 0.5
+    for mod in ("nan", "inf", "huge", "tiny"):
+        dY = torch.randn(n, 64, generator=g) * 1e-3
+        if mod == "nan":
+            dY[17, 3] = float("nan")
+        elif mod == "inf":
+            dY[17, 3] = float("inf")
+        elif mod == "huge":
+            dY *= 1e33
+        else:
+            dY *= 1e-33
+        Xd, Wd = X.to(dev).requires_grad_(), W.to(dev).requires_grad_()
+        ops.linear(Xd, Wd, None).backward(dY.to(dev))
+        dW, dX = Wd.grad.cpu(), Xd.grad.cpu()
+        rW, rX = dY.t() @ X, dY @ W
+        if mod in ("nan", "inf"):
+            assert torch.equal(torch.isfinite(dX), torch.isfinite(rX))
+            assert torch.equal(torch.isfinite(dW), torch.isfinite(rW))
+            fin = torch.isfinite(rX)
+            np.testing.assert_allclose(dX[fin].numpy(), rX[fin].numpy(), rtol=1e-4, atol=1e-9)
+        else:
+            r64W, r64X = dY.double().t() @ X.double(), dY.double() @ W.double()
+            sW, sX = dY.double().abs().t() @ X.double().abs(), dY.double().abs() @ W.double().abs()
+            assert float(((dW.double() - r64W).abs() / sW).max()) <= 1e-6
+            assert float(((dX.double() - r64X).abs() / sX).max()) <= 1e-6
+
+
+def test_linear_split_backward_is_capture_safe_and_deterministic(ops, dev):
+    """the backward's scales and guard live on the device: capturable, replayable on changed gradients, and two runs agree bit
+    for bit (no float atomics: the column maxima go through integer atomicMax, the sums through fixed-order reductions)."""
+    g = torch.Generator().manual_seed(12)
+    X = torch.relu(torch.randn(3000, 4096, generator=g)).to(dev).requires_grad_()
+    W = (torch.randn(64, 4096, generator=g) / 64).to(dev).requires_grad_()
+    b = torch.zeros(64, device=dev, requires_grad=True)
+    G = (torch.randn(3000, 64, generator=g) * 1e-4).to(dev)
+    ops.linear(X, W, b).backward(G)
+    first = [t.grad.clone() for t in (X, W, b)]
+    X.grad = W.grad = b.grad = None
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.linear(X, W, b).backward(G)
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, t in zip(first, (X, W, b)):
+        assert torch.equal(a, t.grad)
+    G.mul_(1e-6)
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = G.double().cpu().t() @ X.detach().double().cpu()
+    sc = G.double().cpu().abs().t() @ X.detach().double().cpu().abs()
+    assert float(((W.grad.double().cpu() - ref).abs() / sc).max()) <= 1e-6
+
+
 @pytest.mark.parametrize("n,F,out,bias", [(300, 96, 256, True), (1000, 256, 256, False), (129, 384, 384, True),
                                           (777, 4096, 256, True)])
 def test_linear_wide_fwd_bwd(ops, dev, n, F, out, bias):

@@ -52,7 +52,9 @@ for step in "$@"; do
              stats_digest $out/headline_kernel_stats.csv 6; head -c 300 $out/bench_headline_only.json; echo ;;
     trace)   rm -rf $out/_trace; base=$(basename ${arg%% *} .py)
              (timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d $out/_trace -- python $arg > $log 2>&1; echo rc=$? >> $log)
-             f=$(find $out/_trace -name "*kernel_stats.csv" | head -1); cp "$f" $out/${base}_kernel_stats.csv; rm -rf $out/_trace
+             f=$(find $out/_trace -name "*kernel_stats.csv" | head -1); cp "$f" $out/${base}_kernel_stats.csv
+             python tools/summarize_trace.py $(find $out/_trace -name "*kernel_trace.csv" | head -1) $out/${base}_kernel_by_grid.csv
+             rm -rf $out/_trace
              tail -5 $log; stats_digest $out/${base}_kernel_stats.csv 30 | tee $out/${base}_kernel_stats.txt ;;
     pmc)     (timeout $T python tools/pmc_kernels.py $arg $out/pmc_${arg%% *} > $log 2>&1; echo rc=$? >> $log); tail -5 $log ;;
     py)      (timeout $T python $arg > $log 2>&1; echo rc=$? >> $log); tail -25 $log ;;

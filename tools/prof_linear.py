@@ -29,6 +29,8 @@ def main():
     for name, n, f in (("baby", 7050, 4096), ("sports", 18357, 4096), ("clothing", 23033, 4096),
                        ("baby-text", 7050, 384), ("clothing-text", 23033, 384), ("vbpr-baby", 7050, 4480),
                        ("c5-shard", 62500, 4096), ("c5", 500000, 4096)):
+        if sys.argv[1:] and name not in sys.argv[1:]:        # python tools/prof_linear.py baby c5 : only these shapes
+            continue
         X = torch.rand(n, f, device=dev, generator=gen)
         W = (torch.rand(64, f, device=dev, generator=gen) - 0.5).requires_grad_()
         b = torch.zeros(64, device=dev, requires_grad=True)
@@ -42,10 +44,16 @@ def main():
             Xg.grad = None
             hip_ops.linear(Xg, W, b).backward(G)
         t_fb = timed(fb, reps)
+        hip_ops.LINEAR_F16X3 = False                       # A/B: the fp32-MFMA kernels (forward, dW, dX)
+        with torch.no_grad():
+            t_f32 = timed(lambda: hip_ops.linear(X, W, b), reps)
+        t_fb32 = timed(fb, reps)
+        hip_ops.LINEAR_F16X3 = True
         fl = 2.0 * n * f * 64
         print("%-14s n=%7d F=%4d  fwd %8.1f us  %6.1f TF/s (%4.1f%% of 157.3)  X %5.2f TB/s | fwd+bwd %8.1f us  %6.1f TF/s"
+              " || fp32-MFMA kernels: fwd %8.1f us, fwd+bwd %8.1f us"
               % (name, n, f, t_f * 1e6, fl / t_f / 1e12, fl / t_f / 157.3e10, n * f * 4 / t_f / 1e12,
-                 t_fb * 1e6, 3 * fl / t_fb / 1e12), flush=True)
+                 t_fb * 1e6, 3 * fl / t_fb / 1e12, t_f32 * 1e6, t_fb32 * 1e6), flush=True)
         del X, W, b, G, Xg
 
 
