@@ -24,13 +24,47 @@ from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
 from mmrec_amd.models.freedom import load_or_build_mm_adj
 
 
+def global_subgraph(norm_adj, q, device, block=2048, tol=1e-3):
+    """PGL's `global_subgraph_extraction` (pgl.py:138-153): rank-(q/4) spectral sub-graph
+        S = U[:, :m] diag(s[:m] * s[q-m:]) V[:, :m]^T,  m = int(0.25 q),  entries with |S| < 1e-3 dropped,
+    from the q leading singular triplets of the normalised adjacency.  The reference takes them from the third-party
+    `sparsesvd` package (SVDLIBC's Lanczos `las2`; not vendored, not pinned in requirements.txt and absent here: parity with
+    ITS rounding is unpinned).  Restated with its published contract -- the q largest singular values in DESCENDING order with
+    their vectors -- on ARPACK (`scipy.sparse.linalg.svds`): S is the same matrix for any orthonormal basis of a repeated
+    singular value's subspace (the symmetric bipartite adjacency has every singular value twice; U and V rotate together and
+    the two weights of a pair are equal), so only entries within rounding of the 1e-3 cut can differ between solvers.
+    The [N, N] product is formed `block` rows at a time (the reference materialises it densely: 2.8 GB at Amazon-Baby size)."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import svds
+    idx, val = norm_adj.to_coo_host()
+    n = norm_adj.n_rows
+    a = sp.csc_matrix((val.astype(np.float64), (idx[0], idx[1])), shape=(n, n))
+    k = min(int(q), n - 2)
+    u, s_, vt = svds(a, k=k, which='LM', tol=1e-10, v0=np.ones(n))      # ascending singular values, deterministic start vector
+    order = np.argsort(-s_, kind='stable')
+    u, s_, vt = u[:, order], s_[order], vt[order]
+    m = int(0.25 * q)
+    w = s_[:m] * s_[k - m:k]
+    left = (u[:, :m] * w[None, :]).astype(np.float32)
+    right = vt[:m].astype(np.float32)
+    rows, cols, vals = [], [], []
+    for r0 in range(0, n, block):
+        blk = left[r0:r0 + block] @ right
+        rr, cc = np.nonzero(np.abs(blk) >= tol)
+        rows.append(rr + r0), cols.append(cc), vals.append(blk[rr, cc])
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    g = hip_ops.CsrGraph.from_coo_host(np.stack([rows, cols]), vals.astype(np.float32), n, n, device)
+    g.transpose()          # not symmetric after the cut in floating point: the backward takes the explicit transpose
+    return g
+
+
 class PGL(FusedEvalMixin, GeneralRecommender):
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
         self.mode = config['mode']
-        if self.mode != 'local':
-            raise NotImplementedError("PGL mode %r: only 'local' (edge-pruned sub-graph) is built; 'global' "
-                                      "depends on the third-party sparsesvd package" % (self.mode,))
+        if self.mode not in ('local', 'global'):
+            raise ValueError("PGL mode %r: 'local' (edge-pruned sub-graph, pgl.py:160-182) or 'global' (spectral sub-graph, "
+                             "pgl.py:138-153)" % (self.mode,))
         self.embedding_dim = config['embedding_size']
         self.feat_embed_dim = config['feat_embed_dim']
         self.knn_k = config['knn_k']
@@ -61,8 +95,12 @@ class PGL(FusedEvalMixin, GeneralRecommender):
         self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
         self.mm_adj = load_or_build_mm_adj(config, self.v_feat, self.t_feat, self.knn_k, self.mm_image_weight,
                                            self.n_items, self.device)
+        if self.mode == 'global':
+            self.sub_graph = global_subgraph(self.norm_adj, self.embedding_dim, self.device)
 
     def pre_epoch_processing(self):
+        if self.mode == 'global':     # the spectral sub-graph is fixed (pgl.py:160: only 'local' re-samples per epoch)
+            return
         keep_len = int(self.edge_values.size(0) * 0.3)
         self.set_kept_edges(torch.multinomial(self.edge_values, keep_len))
 

@@ -327,3 +327,42 @@ def test_freedom_relabelled_id_space_is_the_same_model(tmp_path, golden, how):
         a["model"].eval(), b["model"].eval()
         assert torch.equal(a["model"].full_sort_topk(a["batch"], 20), b["model"].full_sort_topk(b["batch"], 20))
 
+
+def test_pgl_global_mode_spectral_subgraph(tmp_path, golden):
+    """PGL `mode: global` (pgl.py:138-153; the reference needs the third-party `sparsesvd`, absent here and not pinned: parity with
+    its rounding is unpinned).  The plugin's sub-graph -- truncated SVD by ARPACK, formed block by block -- against a plain
+    restatement of the reference's lines on a DENSE numpy SVD of the same normalised adjacency: same entries above the 1e-3 cut
+    (up to entries within 1e-5 of it), values to 1e-5; then one training step and an evaluation run through the plugin."""
+    import numpy as np
+    import torch
+    from mmrec_amd.utils.utils import get_model
+    config, train_data, valid_data = G.setup(tmp_path, golden, "PGL", {"mode": "global", "reg_weight": 1e-3, "dropout": 0.2}, use_gpu=False)
+    model = get_model("PGL")(config, train_data).to("cpu")
+    n, q = model.n_nodes, model.embedding_dim
+    idx, val = model.norm_adj.to_coo_host()
+    A = np.zeros((n, n))
+    A[idx[0], idx[1]] = val
+    ut, s_, vt = np.linalg.svd(A)                       # descending, like sparsesvd
+    m = int(0.25 * q)
+    S = ut[:, :m] @ np.diag(s_[:m] * s_[q - m:q]) @ vt[:m, :]
+    ref = S * (np.abs(S) >= 1e-3)
+    gi, gv = model.sub_graph.to_coo_host()
+    got = np.zeros((n, n))
+    got[gi[0], gi[1]] = gv
+    near_cut = np.abs(np.abs(S) - 1e-3) < 1e-5
+    assert np.array_equal((got != 0) | near_cut, (ref != 0) | near_cut)
+    np.testing.assert_allclose(got[~near_cut], ref[~near_cut], atol=1e-5)
+    assert (ref != 0).sum() > n                          # a real graph, not an empty one
+    model.pre_epoch_processing()                         # a no-op in this mode: the sub-graph is fixed
+    gi2, _ = model.sub_graph.to_coo_host()
+    assert np.array_equal(gi, gi2)
+    loss = model.calculate_loss(G.batch_of(golden, torch.device("cpu")))
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    top = model.full_sort_topk(next(iter(valid_data)), 10)
+    assert top.shape[1] == 10
+    with pytest.raises(ValueError):
+        G.setup(tmp_path / "bad", golden, "PGL", {"mode": "nope"}, use_gpu=False)
+        get_model("PGL")(*G.setup(tmp_path / "bad2", golden, "PGL", {"mode": "nope"}, use_gpu=False)[:2])
+
