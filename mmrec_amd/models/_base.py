@@ -100,6 +100,26 @@ class RelabelledIdsMixin:
 
     relabelled_tables = {}
 
+    def _setup_relabelling(self, config, base_graph):
+        """reads `reorder`; -> graph.BipartiteRelabelling from the model's full normalised user-item graph, or None (key absent / off)"""
+        from mmrec_amd.graph import BipartiteRelabelling
+        how = config['reorder']
+        on = how and str(how).lower() not in ('none', 'false', 'off')
+        self.relabelling = BipartiteRelabelling(base_graph, self.n_users, self.n_items, str(how).lower(), self.device) if on else None
+        return self.relabelling
+
+    def _to_relabelled_rows_(self, param, side):
+        """in place: the plain model's initial values, row `old` at relabelled row perm[old] (same generator consumption as plain)"""
+        rl = self.relabelling
+        inv = rl.inv_u if side == 'u' else rl.inv_i
+        with torch.no_grad():
+            param.copy_(param[inv.to(param.device)])
+
+    def _map_edges(self, edge_indices):
+        """[2, E] (user, item) edge list in the relabelled ids, edge ORDER kept (what the per-epoch multinomial draws from)"""
+        rl = self.relabelling
+        return edge_indices if rl is None else torch.stack([rl.perm_u[edge_indices[0]], rl.perm_i[edge_indices[1]]])
+
     def _map_batch(self, interaction):
         rl = self.relabelling
         if rl is None:

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from mmrec_amd import hip_ops
 from mmrec_amd.common.lazy_rows import LazyRowEmbedding, lazy_adam_enabled
-from mmrec_amd.graph import (BipartiteRelabelling, knn_normalized_coo, mask_to_csr_device, norm_adj_graph, relabel_graph,
+from mmrec_amd.graph import (knn_normalized_coo, mask_to_csr_device, norm_adj_graph, relabel_graph,
                              sparse_coo_to_graph)
 from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
 
@@ -94,9 +94,7 @@ class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRe
         self.norm_adj = norm_adj_graph(self.interaction_matrix, self.n_users, self.n_items, self.device)
         # new key `reorder` (community | degree | rcm): every id-indexed table lives in an id space relabelled once, here, for
         # gather locality (models/_base.py: RelabelledIdsMixin); the graphs are relabelled with their rows' nonzero order kept
-        how = config['reorder']
-        self.relabelling = rl = (BipartiteRelabelling(self.norm_adj, self.n_users, self.n_items, str(how).lower(), self.device)
-                                 if how and str(how).lower() not in ('none', 'false', 'off') else None)
+        rl = self._setup_relabelling(config, self.norm_adj)
         if rl is not None:
             self.norm_adj = relabel_graph(self.norm_adj, rl.node_perm_host())
         self.masked_adj, self.mm_adj = None, None

@@ -15,12 +15,14 @@ import torch.nn as nn
 from mmrec_amd import hip_ops
 from mmrec_amd.graph import norm_adj_graph
 from mmrec_amd.utils.utils import random_sample_range
-from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender
+from mmrec_amd.graph import relabel_graph
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
 
 
-class LayerGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
+class LayerGCN(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
     adjacent_tables = ('user_embeddings', 'item_embeddings')
+    relabelled_tables = {'user_embeddings': 'u', 'item_embeddings': 'i'}     # config key `reorder`
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -42,6 +44,11 @@ class LayerGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         self.edge_values = hip_ops.edge_norm_values(self.edge_indices[0].contiguous(),
                                                     self.edge_indices[1].contiguous(),
                                                     self.n_users, self.n_items)
+        if self._setup_relabelling(config, self.norm_adj_matrix) is not None:      # new key `reorder` (models/_base.py)
+            self.norm_adj_matrix = relabel_graph(self.norm_adj_matrix, self.relabelling.node_perm_host())
+            self.edge_indices = self._map_edges(self.edge_indices)
+            self._to_relabelled_rows_(self.user_embeddings, 'u')
+            self._to_relabelled_rows_(self.item_embeddings, 'i')
 
     def pre_epoch_processing(self):
         if self.dropout <= .0:
@@ -72,6 +79,7 @@ class LayerGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         return self.forward()
 
     def calculate_loss(self, interaction):
+        interaction = self._map_batch(interaction)
         user, pos, neg = interaction[0], interaction[1], interaction[2]
         self.forward_adj = self.masked_adj
         u_all, i_all = self.forward()

@@ -10,13 +10,15 @@ import torch.nn as nn
 
 from mmrec_amd import hip_ops
 from mmrec_amd.graph import norm_adj_graph
-from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, emb_loss_rows
+from mmrec_amd.graph import relabel_graph
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin, emb_loss_rows
 
 
-class LightGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
+class LightGCN(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
 
     adjacent_tables = ('embedding_dict.user_emb', 'embedding_dict.item_emb')
+    relabelled_tables = {'embedding_dict.user_emb': 'u', 'embedding_dict.item_emb': 'i'}     # config key `reorder`
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -29,6 +31,10 @@ class LightGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
             'user_emb': nn.Parameter(init(torch.empty(self.n_users, self.latent_dim))),
             'item_emb': nn.Parameter(init(torch.empty(self.n_items, self.latent_dim)))})
         self.norm_adj_matrix = norm_adj_graph(self.interaction_matrix, self.n_users, self.n_items, self.device)
+        if self._setup_relabelling(config, self.norm_adj_matrix) is not None:      # new key `reorder` (models/_base.py)
+            self.norm_adj_matrix = relabel_graph(self.norm_adj_matrix, self.relabelling.node_perm_host())
+            self._to_relabelled_rows_(self.embedding_dict['user_emb'], 'u')
+            self._to_relabelled_rows_(self.embedding_dict['item_emb'], 'i')
 
     def get_ego_embeddings(self):
         return torch.cat([self.embedding_dict['user_emb'], self.embedding_dict['item_emb']], 0)
@@ -40,6 +46,7 @@ class LightGCN(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     eval_embeddings = forward
 
     def calculate_loss(self, interaction):
+        interaction = self._map_batch(interaction)
         user, pos, neg = interaction[0], interaction[1], interaction[2]
         u_all, i_all = self.forward()
         mf_loss = hip_ops.bpr_loss(u_all, i_all, user, pos, neg, hip_ops.BPR_GAMMA, 'mean')

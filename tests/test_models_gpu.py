@@ -1256,3 +1256,38 @@ def test_freedom_relabelled_id_space_is_bitwise_the_plain_model(tmp_path, golden
             else:
                 torch.testing.assert_close(b[1][n], a[1][n], rtol=1e-5, atol=1e-9, msg=n)
 
+
+@pytest.mark.parametrize("name,extra,keep", [("LightGCN", {"n_layers": 3, "reg_weight": 1e-4}, None),
+                                             ("LayerGCN", {"n_layers": 4, "reg_weight": 1e-3, "dropout": 0.1}, "lay_keep_idx")])
+def test_relabelled_id_space_other_plugins_on_device(tmp_path, golden, name, extra, keep):
+    """config `reorder` in LightGCN / LayerGCN on the device: loss and evaluation tables bit for bit the plain plugin's, top-K
+    lists identical, state_dict in the dataset's row order, gradients (atomic scatters) within rounding after un-permuting"""
+    if not USE_GPU:
+        pytest.skip("CPU twin: tests/test_models_cpu.py::test_relabelled_id_space_other_plugins")
+    res = {}
+    for key in (None, "degree", "community"):
+        ex = dict(extra, hip_graph_step=False)
+        if key:
+            ex["reorder"] = key
+        config, train_data, valid_data, model = build(tmp_path / ("r%s" % key), golden, name, ex)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        if keep:
+            model.set_kept_edges(torch.as_tensor(golden[keep]).to(model.device))
+        loss = model.calculate_loss(batch_of(golden, model.device))
+        loss.backward()
+        rl = model.relabelling
+        grads = {n: (p.grad.index_select(0, rl.perm_u if model.relabelled_tables[n] == "u" else rl.perm_i)
+                     if (rl is not None and n in model.relabelled_tables) else p.grad).clone() for n, p in model.named_parameters()}
+        model.eval()
+        u, i = model.eval_embeddings()
+        if rl is not None:
+            u, i = u.index_select(0, rl.perm_u), i.index_select(0, rl.perm_i)
+        res[key] = (sd0, loss.detach().clone(), grads, model.full_sort_topk(next(iter(valid_data)), 20).clone(), u.clone(), i.clone())
+    for key in ("degree", "community"):
+        a, b = res[None], res[key]
+        for k in a[0]:
+            assert torch.equal(a[0][k], b[0][k]), k
+        assert torch.equal(a[1], b[1]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]) and torch.equal(a[3], b[3])
+        for n in a[2]:
+            torch.testing.assert_close(b[2][n], a[2][n], rtol=1e-5, atol=1e-9, msg=n)
+
