@@ -15,6 +15,7 @@
 #   pmc:<workload>         python tools/pmc_kernels.py <workload> (topk | linear | spmm): counters in their own passes
 #   py:<script+args>       python <script args>
 #   list_avail:<regex>     rocprofv3 --list-avail | grep -i <regex>
+#   env:VAR=VALUE          export VAR=VALUE for the steps that follow
 # env: STEP_TIMEOUT (seconds per step, default 900)
 tag=${1:?tag}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -58,6 +59,7 @@ for step in "$@"; do
              tail -5 $log; stats_digest $out/${base}_kernel_stats.csv 30 | tee $out/${base}_kernel_stats.txt ;;
     pmc)     (timeout $T python tools/pmc_kernels.py $arg $out/pmc_${arg%% *} > $log 2>&1; echo rc=$? >> $log); tail -5 $log ;;
     py)      (timeout $T python $arg > $log 2>&1; echo rc=$? >> $log); tail -25 $log ;;
+    env)     export "$arg"; echo "exported $arg" ;;
     list_avail) (timeout 120 rocprofv3 --list-avail 2>&1 | grep -i -E "$arg" > $log; echo rc=$? >> $log); head -40 $log ;;
     *)       echo "unknown step $step" ;;
   esac
