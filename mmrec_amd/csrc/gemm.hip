@@ -1174,12 +1174,16 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     else
         hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, 0, Wt_sp, wcs_inv, cells, redo, ncb);
     if (dW) {
+        float* part = w.nsplit == 1 ? dW : slabs;
+        // (A form in which every dW workgroup scans its own item chunk of dY for the scales and splits dY in registers -- no
+        // column-maxima launch, no transposed split, no dY^T workspace -- was built, passed the same tests and LOST: 34.9 us
+        // against 24.3 + 6.9 + 5.0 us at Amazon-Baby size, forward + backward 114 against 110 us as a hipGraph replay:
+        // profiles/r05_linear_bwd_fused_dw_ab.log; the code is in the history.)
         int cb = ceil_div(n, 64);                // >= 4 rows per thread-row; every workgroup ends with 64 atomicMax on the 64 cells
         if (cb > 256) cb = 256;
         hipLaunchKernelGGL(bwd_dy_colmax_kernel, dim3(cb), dim3(256), 0, s, dY, n, cells);
         hipLaunchKernelGGL(bwd_dy_tsplit_kernel, dim3(w.ndb), dim3(256), 0, s, dY, n, (const unsigned*)cells, dYt,
                            db ? dbp : (float*)nullptr, w.nblk, w.tb);
-        float* part = w.nsplit == 1 ? dW : slabs;
         hipLaunchKernelGGL(bwd_w_f16x3_kernel, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
                            (const unsigned*)cells, n, F, w.chunk);
         if (w.nsplit > 1)
