@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) void bwd_dy_tsplit_kernel(const float* __restr
 // wave w owns the 32 columns f0 + 32 w .. and all 64 outputs.  A fragments come ready from the pre-split dY tile (one 16-B LDS
 // read per 8 items), B fragments are 8 lane-consecutive ds_read_b32 of the fp32 X tile, split in registers.  Same 3-stage LDS-DMA
 // ring as linear_bwd_w_dma_kernel (X tile natural [item][f], G tile 8 KB linear).  Needs n_chunk * F * 4 < 2^31.
+template <bool NT>     // NT: X does not fit the Infinity Cache and is read once per call: streamed non-temporal (as in the forward)
 __global__ __launch_bounds__(256, 2) void bwd_w_f16x3_kernel(const float* __restrict__ dYt_sp, const float* __restrict__ X,
                                                              float* __restrict__ part, int* __restrict__ redo,
                                                              const unsigned* __restrict__ cells, int n, int F, int n_chunk) {
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void bwd_w_f16x3_kernel(const float* __rest
     auto issue = [&](float* gs, float* xs, int t) {
         const int sx = t * BW_BK * F * 4, sg = t * 8192;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16<false>(rx, lds_addr(xs + (4 * wave + j) * 256), vx[j], sx);
+        for (int j = 0; j < 4; ++j) lds_dma16<NT>(rx, lds_addr(xs + (4 * wave + j) * 256), vx[j], sx);
 #pragma unroll
         for (int j = 0; j < 2; ++j) lds_dma16<false>(rg, lds_addr(gs + (2 * wave + j) * 256), (2 * wave + j) * 1024 + lane * 16, sg);
     };
@@ -882,6 +883,7 @@ __global__ __launch_bounds__(256) void bwd_w_reduce_kernel(const float* __restri
 // split -- in registers for the whole walk and issue LDS reads, 12 MFMAs and 16 row-segment stores per 32-column sub-tile; wave 4
 // brings the pre-split W^T tiles (32 KB, linear) and their 128 column scales by LDS-DMA into a double buffer and is the only wave
 // that waits on vmcnt.  Output-write bound: n F 4 bytes.
+template <int STORE_AUX>     // cache policy bits of the dX stores (2 = nt: a dX larger than the Infinity Cache is written once and not re-read here)
 __global__ __launch_bounds__(320, 2) void bwd_x_f16x3_kernel(const float* __restrict__ dY, const float* __restrict__ Wt_sp,
                                                              const float* __restrict__ wcs_inv, float* __restrict__ dX, int n,
                                                              int F, int ftiles) {
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(320, 2) void bwd_x_f16x3_kernel(const float* __rest
                 const int rr = (r & 3) + 8 * (r >> 2);
                 const float v = fmaf(cx[r], 1.f / 2048.f, hh[r]) * (rs16[r] * cinv);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdx, (int)lane_off,
-                                                      (wave * 32 + rr) * F * 4 + tcol + t * 128, 0);
+                                                      (wave * 32 + rr) * F * 4 + tcol + t * 128, STORE_AUX);
             }
         }
     };
@@ -1132,6 +1134,10 @@ inline BwdSplitWs bwd_split_ws(int n, int F) {
     w.total = off;
     return w;
 }
+#ifndef MMREC_BWD_NT
+#define MMREC_BWD_NT 1     // bit 0 = dW reads an X larger than the Infinity Cache non-temporal (measured: -14 % forward + backward at Sports / Clothing size), bit 1 = dX written non-temporal (measured: +4 ... +12 % at 62,500 / 500,000 rows: off); profiles/r05_linear_bwd_nt_ab.log, tools/prof_linear.py run-variants
+#endif
+constexpr bool BWD_X_NT_STORES = (MMREC_BWD_NT & 2) != 0;
 inline bool bwd_split_serves(int n, int F, int out) { return out == 64 && n > 0 && F > 0 && (F % BW_BF) == 0; }
 }  // namespace
 
@@ -1168,6 +1174,7 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     float* dbp = reinterpret_cast<float*>(base + w.dbp);
     float* slabs = reinterpret_cast<float*>(base + w.slabs);
     const int ncb = F / BW_BF;
+    const bool big = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);      // X / dX larger than the Infinity Cache
     // (also clears the cells / redo flags the dW path uses; W may be NULL when only dW is wanted: then the kernel only clears)
     if (dX)
         hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv, cells, redo, ncb);
@@ -1184,8 +1191,12 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
         hipLaunchKernelGGL(bwd_dy_colmax_kernel, dim3(cb), dim3(256), 0, s, dY, n, cells);
         hipLaunchKernelGGL(bwd_dy_tsplit_kernel, dim3(w.ndb), dim3(256), 0, s, dY, n, (const unsigned*)cells, dYt,
                            db ? dbp : (float*)nullptr, w.nblk, w.tb);
-        hipLaunchKernelGGL(bwd_w_f16x3_kernel, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
-                           (const unsigned*)cells, n, F, w.chunk);
+        if (big && (MMREC_BWD_NT & 1))
+            hipLaunchKernelGGL(bwd_w_f16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
+                               (const unsigned*)cells, n, F, w.chunk);
+        else
+            hipLaunchKernelGGL(bwd_w_f16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
+                               (const unsigned*)cells, n, F, w.chunk);
         if (w.nsplit > 1)
             hipLaunchKernelGGL(bwd_w_reduce_kernel, dim3((unsigned)(((size_t)64 * F / 4 + 255) / 256)), dim3(256), 0, s,
                                (const float*)slabs, w.nsplit, F, dW, redo);
@@ -1198,8 +1209,12 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
         const int rt = ceil_div(n, 128), nft = F / 128;
         int ftiles = 8;
         while (ftiles > 1 && (long)rt * ceil_div(nft, ftiles) < 192) ftiles >>= 1;
-        hipLaunchKernelGGL(bwd_x_f16x3_kernel, dim3(rt, ceil_div(nft, ftiles)), dim3(320), 0, s, dY, (const float*)Wt_sp,
-                           (const float*)wcs_inv, dX, n, F, ftiles);
+        if (big && BWD_X_NT_STORES)
+            hipLaunchKernelGGL(bwd_x_f16x3_kernel<2>, dim3(rt, ceil_div(nft, ftiles)), dim3(320), 0, s, dY, (const float*)Wt_sp,
+                               (const float*)wcs_inv, dX, n, F, ftiles);
+        else
+            hipLaunchKernelGGL(bwd_x_f16x3_kernel<0>, dim3(rt, ceil_div(nft, ftiles)), dim3(320), 0, s, dY, (const float*)Wt_sp,
+                               (const float*)wcs_inv, dX, n, F, ftiles);
     }
     MMREC_RETURN_LAUNCH_STATUS();
 }

@@ -57,5 +57,44 @@ def main():
         del X, W, b, G, Xg
 
 
+VARIANTS = {"nt0": 0, "nt1_dw_reads": 1, "nt2_dx_stores": 2, "nt3_both": 3}    # -DMMREC_BWD_NT=<bits> builds of gemm.hip
+
+
+def build_variants():
+    """python tools/prof_linear.py build-variants   (here, no GPU): tools/probe_libs/libmmrec_bwd_<name>.so"""
+    import subprocess
+    from mmrec_amd import build as b
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_libs")
+    os.makedirs(out, exist_ok=True)
+    b.build(verbose=False)
+    objs = [os.path.join(b.OBJ, s.replace(".hip", ".o")) for s in b.SOURCES if s != "gemm.hip"]
+    for name, bits in VARIANTS.items():
+        o = os.path.join(out, "gemm_%s.o" % name)
+        subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DMMREC_BWD_NT=%d" % bits, "-c", os.path.join(b.CSRC, "gemm.hip"), "-o", o])
+        subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                               os.path.join(out, "libmmrec_bwd_%s.so" % name)] + objs + [o])
+        os.remove(o)
+        print("built", name, flush=True)
+
+
+def run_variants(shapes):
+    """python tools/prof_linear.py run-variants [shapes...]   (GPU): every variant library in its own process, twice"""
+    import subprocess
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_libs")
+    for rnd in range(2):
+        for name in VARIANTS:
+            env = dict(os.environ, MMREC_HIP_LIB=os.path.join(out, "libmmrec_bwd_%s.so" % name))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + shapes, env=env, capture_output=True, text=True)
+            for line in r.stdout.strip().splitlines():
+                print("%-14s %s" % (name, line), flush=True)
+            if r.returncode:
+                print(name, "FAILED", r.stderr[-400:])
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:2] == ["build-variants"]:
+        build_variants()
+    elif sys.argv[1:2] == ["run-variants"]:
+        run_variants(sys.argv[2:])
+    else:
+        main()
