@@ -221,8 +221,13 @@ int mmrec_linear_fwd_split_f32(const float* X, const float* W, const float* b, f
  * fixed order), dX [n, F] = dY W  (autograd of nn.Linear: freedom.py:58-62,205,208; bm3.py:51-56; lattice.py:90-92).  dW (with
  * db or without) and dX may each be NULL (not wanted).  The operands are brought into fp16's range by exact power-of-two
  * scales (per column of dY for dW, per row of dY and per column of W for dX), X is taken as it is with the forward's guard
- * per 128-column block (fp32 fix-up on the device); inf / NaN propagate.  out == 64 and F % 128 == 0 run these kernels, every
- * other shape is handed to mmrec_linear_bwd_w_f32 / mmrec_linear_bwd_x_f32.  Deterministic (no float atomics).
+ * per 128-column block (fp32 fix-up on the device); inf / NaN propagate.  Accuracy: |err| <= 2^-21 sum |a b| per output as long
+ * as every contributing operand entry lies within 2^26 of the magnitude its row / column was scaled to; smaller entries carry an
+ * absolute error of 2^-36 of that magnitude (negligible norm-wise).  For dW this is GUARDED: a column of dY whose non-zero
+ * entries span more than 2^26 sends the whole dW to the fp32 kernel (device-side decision, found by the randomized test: such
+ * entries matter where X is zero at the large entries' items); for dX (rows of dY, columns of W) it is not.
+ * out == 64 and F % 128 == 0 run these kernels, every other shape is handed to mmrec_linear_bwd_w_f32 / mmrec_linear_bwd_x_f32.
+ * Deterministic (no float atomics).
  * workspace: mmrec_linear_bwd_split_workspace_bytes (>= mmrec_linear_workspace_bytes). */
 size_t mmrec_linear_bwd_split_workspace_bytes(int32_t n, int32_t F, int32_t out);
 int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const float* W, float* dW, float* db, float* dX, int32_t n,

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
                                                            int n_chunk, int ldg, const int* __restrict__ redo) {
     __shared__ __attribute__((aligned(16))) float Gs[BW_BK][64];
     __shared__ __attribute__((aligned(16))) float Xs[BW_BK][BW_BF];
-    if (redo && !redo[blockIdx.x]) return;      // fix-up launch of mmrec_linear_bwd_split_f32: flagged 128-column blocks only
+    if (redo && !(redo[blockIdx.x] | redo[gridDim.x])) return;      // fix-up launch of mmrec_linear_bwd_split_f32: flagged 128-column blocks only (redo[last]: all of them)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * BW_BF;
     const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restri
                                                            float* __restrict__ wcs_inv, unsigned* __restrict__ cells,
                                                            int* __restrict__ redo, int n_redo) {
     if (blockIdx.x == 0) {
-        if (threadIdx.x < 64) cells[threadIdx.x] = 0u;
+        if (threadIdx.x < 64) { cells[threadIdx.x] = 0u; cells[64 + threadIdx.x] = 0x7f800000u; }      // column maxima / minima of |dY|
         for (int j = threadIdx.x; j < n_redo; j += 256) redo[j] = 0;
     }
     const int f = blockIdx.x * 256 + threadIdx.x;
@@ -699,27 +699,33 @@ __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restri
     }
 }
 
-// cells[o] = max_i |dY[i][o]| as the bit pattern of a non-negative float (monotone as unsigned; a NaN's pattern is larger than
-// inf's, so non-finite entries surface as ex == 255 in pow2_scale).  Grid-stride over rows, one atomicMax per column and block.
+// cells[o] = max_i |dY[i][o]|, cells[64 + o] = min over the NON-ZERO entries, both as bit patterns of non-negative floats
+// (monotone as unsigned; a NaN's pattern is larger than inf's, so non-finite entries surface as ex == 255 in pow2_scale).
+// Grid-stride over rows, one atomicMax + one atomicMin per column and block.  The minimum is the dW path's range guard: one scale
+// per column keeps 22 bits only for entries within 2^26 of the column's maximum (bwd_dy_tsplit_kernel decides).
 __global__ __launch_bounds__(256) void bwd_dy_colmax_kernel(const float* __restrict__ dY, int n, unsigned* __restrict__ cells) {
-    __shared__ unsigned red[16][64];
+    __shared__ unsigned red[16][64], redn[16][64];
     const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
-    unsigned m[4] = {0u, 0u, 0u, 0u};
-    for (int row = blockIdx.x * 16 + r0; row < n; row += gridDim.x * 16) {       // (grid: <= 128 workgroups, see the launch)
+    unsigned m[4] = {0u, 0u, 0u, 0u}, mn[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u};
+    for (int row = blockIdx.x * 16 + r0; row < n; row += gridDim.x * 16) {       // (grid: <= 256 workgroups, see the launch)
         const float4 v = reinterpret_cast<const float4*>(dY)[(size_t)row * 16 + c4];
-        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu);
-        m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
-        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu);
-        m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+        const unsigned u[4] = {__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu,
+                               __float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m[e] = max(m[e], u[e]);
+            mn[e] = min(mn[e], u[e] ? u[e] : 0x7f800000u);
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[r0][4 * c4 + e] = m[e];
+    for (int e = 0; e < 4; ++e) { red[r0][4 * c4 + e] = m[e]; redn[r0][4 * c4 + e] = mn[e]; }
     __syncthreads();
     if (threadIdx.x < 64) {
-        unsigned t = 0u;
+        unsigned t = 0u, tn = 0x7f800000u;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t = max(t, red[k][threadIdx.x]);
+        for (int k = 0; k < 16; ++k) { t = max(t, red[k][threadIdx.x]); tn = min(tn, redn[k][threadIdx.x]); }
         if (t) atomicMax(cells + threadIdx.x, t);
+        if (tn != 0x7f800000u) atomicMin(cells + 64 + threadIdx.x, tn);
     }
 }
 
@@ -730,9 +736,16 @@ __global__ __launch_bounds__(256) void bwd_dy_colmax_kernel(const float* __restr
 // (bias gradient; db_reduce_kernel sums the workgroups' partials in order).
 __global__ __launch_bounds__(256) void bwd_dy_tsplit_kernel(const float* __restrict__ dY, int n, const unsigned* __restrict__ cells,
                                                             float* __restrict__ dYt_sp, float* __restrict__ dbpart, int nblk,
-                                                            int BWD_TB) {
+                                                            int BWD_TB, int* __restrict__ redo_all) {
     __shared__ __attribute__((aligned(16))) float Gs[32][64 + 1];
     const int tid = threadIdx.x;
+    // range guard of the dW path: a column whose non-zero entries span more than 2^26 (exponent fields 26 apart) cannot keep
+    // fp32's relative accuracy for its small entries under ONE scale -- they matter where X is zero at the large ones' items --
+    // so the whole dW is then left to the fp32 fix-up kernel (redo_all; gradients of one batch span a few decades, not eight)
+    if (blockIdx.x == 0 && tid < 64) {
+        const unsigned mx = cells[tid], mn = cells[64 + tid];
+        if (mx < 0x7f800000u && mn < mx && (mx >> 23) - (mn >> 23) > 26u) *redo_all = 1;
+    }
     const int o = tid >> 2, q = tid & 3;
     float sc, inv;
     pow2_scale(__uint_as_float(cells[o]), 14, sc, inv);
@@ -1101,7 +1114,7 @@ extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const 
 }
 
 // ---- ABI 11: the projection's backward on the 16-bit matrix cores (see the kernels' comment block) ----------------------------
-// Workspace layout (mmrec_linear_bwd_split_workspace_bytes): [W^T split: F x 256 B][wcs_inv: F + 256 floats][cells: 64 u32]
+// Workspace layout (mmrec_linear_bwd_split_workspace_bytes): [W^T split: F x 256 B][wcs_inv: F + 256 floats][cells: 64 column maxima + 64 minima, u32]
 // [redo: F / 128 + 1 ints][dY^T split tiles: ceil(n / 32) x 8 KB][db partials: <= 1024 x 64 floats][dW slabs: nsplit > 1 ?
 // nsplit x 64 x F floats]; never smaller than what the fp32 entry points need (shapes they serve).
 namespace {
@@ -1122,7 +1135,7 @@ inline BwdSplitWs bwd_split_ws(int n, int F) {
     size_t off = 0;
     w.wt = off; off += al256((size_t)F * 256);
     w.wcs = off; off += al256(((size_t)F + 256) * 4);
-    w.cells = off; off += 256;
+    w.cells = off; off += 512;
     w.redo = off; off += al256(((size_t)F / BW_BF + 1) * 4);
     w.dyt = off; off += al256((size_t)w.nblk * 8192);
     w.tb = w.nblk / 512;
@@ -1177,9 +1190,9 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     const bool big = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);      // X / dX larger than the Infinity Cache
     // (also clears the cells / redo flags the dW path uses; W may be NULL when only dW is wanted: then the kernel only clears)
     if (dX)
-        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv, cells, redo, ncb);
+        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv, cells, redo, ncb + 1);
     else
-        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, 0, Wt_sp, wcs_inv, cells, redo, ncb);
+        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, 0, Wt_sp, wcs_inv, cells, redo, ncb + 1);
     if (dW) {
         float* part = w.nsplit == 1 ? dW : slabs;
         // (A form in which every dW workgroup scans its own item chunk of dY for the scales and splits dY in registers -- no
@@ -1190,7 +1203,7 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
         if (cb > 256) cb = 256;
         hipLaunchKernelGGL(bwd_dy_colmax_kernel, dim3(cb), dim3(256), 0, s, dY, n, cells);
         hipLaunchKernelGGL(bwd_dy_tsplit_kernel, dim3(w.ndb), dim3(256), 0, s, dY, n, (const unsigned*)cells, dYt,
-                           db ? dbp : (float*)nullptr, w.nblk, w.tb);
+                           db ? dbp : (float*)nullptr, w.nblk, w.tb, redo + ncb);
         if (big && (MMREC_BWD_NT & 1))
             hipLaunchKernelGGL(bwd_w_f16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
                                (const unsigned*)cells, n, F, w.chunk);
