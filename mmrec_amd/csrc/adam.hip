@@ -6,7 +6,7 @@
 #include "common.h"
 #include <limits.h>
 
-#ifndef MMREC_ADAM_NO_SETTLED    // probe build (tools/gpu_r4_y.sh): the catch-up always replays the full element-step
+#ifndef MMREC_ADAM_NO_SETTLED    // probe build (-DMMREC_ADAM_NO_SETTLED=1; profiles/r04_c5_steady_state_settled_replay_ab.log): the catch-up always replays the full element-step
 #define MMREC_ADAM_NO_SETTLED 0
 #endif
 
