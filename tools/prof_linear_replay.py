@@ -4,6 +4,7 @@ A/B runs of whole-library variants in ONE lease:
 
     python tools/prof_linear_replay.py [n=7050] [F=4096]                 # the library in the tree (or MMREC_HIP_LIB)
     python tools/prof_linear_replay.py ab libA.so libB.so [n] [F]        # alternating, three rounds, each in its own process
+    python tools/prof_linear_replay.py fork [n] [F]                      # hip_ops.LINEAR_BWD_FORK off / on, alternating
 """
 import os
 import subprocess
@@ -17,6 +18,9 @@ def one(n, F):
     import numpy as np
     import torch
     from mmrec_amd import hip_ops
+    if os.environ.get("MMREC_LINEAR_BWD_FORK") is not None and hasattr(hip_ops, "LINEAR_BWD_FORK"):
+        # (A/B of a two-stream backward that was built and removed in round 5: profiles/r05_linear_bwd_fork_ab.log)
+        hip_ops.LINEAR_BWD_FORK = os.environ["MMREC_LINEAR_BWD_FORK"] == "1"
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(0)
     X = torch.rand(n, F, device=dev, generator=gen).requires_grad_()
@@ -60,5 +64,11 @@ if __name__ == "__main__":
                 r = subprocess.run([sys.executable, os.path.abspath(__file__)] + rest, env=dict(os.environ, MMREC_HIP_LIB=os.path.abspath(lib)),
                                    capture_output=True, text=True)
                 print("%-40s %s" % (os.path.basename(lib), r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "FAILED " + r.stderr[-300:]), flush=True)
+    elif sys.argv[1:2] == ["fork"]:
+        for rnd in range(3):
+            for flag in ("0", "1"):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[2:], env=dict(os.environ, MMREC_LINEAR_BWD_FORK=flag),
+                                   capture_output=True, text=True)
+                print("LINEAR_BWD_FORK=%s  %s" % (flag, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "FAILED " + r.stderr[-300:]), flush=True)
     else:
         one(int(sys.argv[1]) if len(sys.argv) > 1 else 7050, int(sys.argv[2]) if len(sys.argv) > 2 else 4096)
