@@ -1022,12 +1022,28 @@ inline void pick_split(int tiles, int extent, int gran, int* nsplit, int* chunk)
     *chunk = best_c;
 }
 
+// The split-operand kernels stream X at 4-5 TB/s and are not bound per CU: measured (tools/prof_linear_replay.py, same lease,
+// forced split counts: profiles/r05_linear_split_counts_ab.log) they want about ONE workgroup per CU and the longest chunks that
+// still give that -- 8 / 4 / 2 k-splits of the forward at 4,096 / 7,050 / 23,033 rows (the fp32 cost model above picks 16 / 8 / 4)
+// and 8 item-splits of dW at every size (16): -7.6 % forward + backward at 4,096 rows, -2.7 % at 7,050, -3.5 % at 23,033.
+inline void pick_split_stream(int tiles, int extent, int gran, int* nsplit, int* chunk) {
+    int s = 256 / tiles;                                   // at most one workgroup per CU ...
+    if (s < 2) s = tiles <= 200 ? 2 : 1;                   // ... but two chunks while a single one would leave a fifth of the chip idle
+    const int max_s = ceil_div(extent, 2 * gran);          // a chunk is at least two tiles of the ring
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    *chunk = ceil_div(ceil_div(extent, s), gran) * gran;
+    *nsplit = ceil_div(extent, *chunk);
+}
+
 }  // namespace
 
 extern "C" size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out) {
     if (n <= 0 || F <= 0 || out <= 0 || (out & 63)) return 0;   // out > 64: only the dW call uses it
-    int s1, c1, s2, c2;
+    int s1, c1, s2, c2, s1s, c1s;
     pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &s1, &c1);
+    pick_split_stream(ceil_div(n, LIN_BM), F, LIN_BK, &s1s, &c1s);      // (the split-operand forward's rule)
+    if (s1s > s1) s1 = s1s;
     pick_split(ceil_div(F, BW_BF), n, BW_BK, &s2, &c2);
     // forward: partial slabs, then (mmrec_linear_fwd_split_f32) the 64 x F split copy of W, the per-slab row maxima of |X| and
     // the redo flags of its domain check (one per 128-row block + one per W row)
@@ -1084,7 +1100,10 @@ extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const 
     if (n == 0) return 0;
     if (!X || !W || !Y || !workspace) return MMREC_ERR_BAD_ARG;
     int nsplit, chunk;
-    pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &nsplit, &chunk);
+    pick_split_stream(ceil_div(n, LIN_BM), F, LIN_BK, &nsplit, &chunk);
+#ifdef MMREC_FWD_SPLIT      // probe (tools/prof_linear_replay.py ab): force the split-K count
+    chunk = ceil_div(ceil_div(F, MMREC_FWD_SPLIT), LIN_BK) * LIN_BK; nsplit = ceil_div(F, chunk);
+#endif
     hipStream_t s = mmrec_stream(stream);
     const int nblocks = ceil_div(n, LIN_BM);
     float* part = static_cast<float*>(workspace);
@@ -1125,7 +1144,10 @@ struct BwdSplitWs {
 inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 inline BwdSplitWs bwd_split_ws(int n, int F) {
     BwdSplitWs w;
-    pick_split(ceil_div(F, BW_BF), n, BW_BK, &w.nsplit, &w.chunk);
+    pick_split_stream(ceil_div(F, BW_BF), n, BW_BK, &w.nsplit, &w.chunk);
+#ifdef MMREC_BWD_W_SPLIT    // probe: force the split-over-items count of the dW kernel
+    w.chunk = ceil_div(ceil_div(n, MMREC_BWD_W_SPLIT), BW_BK) * BW_BK; w.nsplit = ceil_div(n, w.chunk);
+#endif
     // LDS-DMA scalar offsets of the dW kernel: a workgroup's item chunk must stay below 2^31 bytes of X
     while ((size_t)w.chunk * F * 4 >= ((size_t)1 << 31)) {
         w.chunk = ceil_div(w.chunk / 2, BW_BK) * BW_BK;

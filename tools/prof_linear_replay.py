@@ -3,7 +3,7 @@
 A/B runs of whole-library variants in ONE lease:
 
     python tools/prof_linear_replay.py [n=7050] [F=4096]                 # the library in the tree (or MMREC_HIP_LIB)
-    python tools/prof_linear_replay.py ab libA.so libB.so [n] [F]        # alternating, three rounds, each in its own process
+    python tools/prof_linear_replay.py ab libA.so libB.so ... [n] [F]    # alternating, three rounds, each in its own process
     python tools/prof_linear_replay.py fork [n] [F]                      # hip_ops.LINEAR_BWD_FORK off / on, alternating
 """
 import os
@@ -58,7 +58,8 @@ def one(n, F):
 
 if __name__ == "__main__":
     if sys.argv[1:2] == ["ab"]:
-        libs, rest = sys.argv[2:4], sys.argv[4:]
+        libs = [a for a in sys.argv[2:] if a.endswith(".so")]
+        rest = [a for a in sys.argv[2:] if not a.endswith(".so")]
         for rnd in range(3):
             for lib in libs:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__)] + rest, env=dict(os.environ, MMREC_HIP_LIB=os.path.abspath(lib)),
