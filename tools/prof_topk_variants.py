@@ -18,6 +18,7 @@ VARIANTS = {          # name -> defines
     "current": [],                                # the tree as it is (pass 1 on every second stage from 131,072 candidates on)
     "final16": ["-DMMREC_TF_FINAL_ROWS=16"],      # final kernel: 16 instead of 8 candidate rows in flight per lane (116 instead of 68 VGPRs)
     "final12": ["-DMMREC_TF_FINAL_ROWS=12"],
+    "final4": ["-DMMREC_TF_FINAL_ROWS=4"],        # fewer rows in flight, fewer registers, more resident waves
 }
 
 
