@@ -1384,7 +1384,7 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                         if kname.startswith(("bwd_x_f16x3", "gemm64_stream")) and rec.get("duration_us"):
                             rec["write_gbs"] = 4.0 * n_proj * 4096 / (rec["duration_us"] * 1e-6) / 1e9
                             rec["frac_write_roofline"] = rec["write_gbs"] / HBM_PEAK_GBS
-                        if kname.startswith(("bwd_w_f16x3", "linear_bwd_w_dma", "linear_fwd_dma")) and rec.get("duration_us"):
+                        if kname.startswith(("linear_bwd_w_bf16x3", "linear_bwd_w_dma", "linear_fwd_dma")) and rec.get("duration_us"):
                             rec["x_stream_gbs"] = 4.0 * n_proj * 4096 / (rec["duration_us"] * 1e-6) / 1e9
                     pr["counters_source"] = ("in-run: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES, one "
                                              "pass, 4 forward + backward calls at %d items; MfmaUtil_busy_cu = MFMA busy cycles / "

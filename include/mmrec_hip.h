@@ -219,13 +219,18 @@ int mmrec_linear_fwd_split_f32(const float* X, const float* W, const float* b, f
                                int32_t out, void* workspace, mmrec_stream_t stream);
 /* ABI 11 -- the projection's BACKWARD with split operands, one call: dW [64, F] = dY^T X, db [64] = column sums of dY (fp32,
  * fixed order), dX [n, F] = dY W  (autograd of nn.Linear: freedom.py:58-62,205,208; bm3.py:51-56; lattice.py:90-92).  dW (with
- * db or without) and dX may each be NULL (not wanted).  The operands are brought into fp16's range by exact power-of-two
- * scales (per column of dY for dW, per row of dY and per column of W for dX), X is taken as it is with the forward's guard
- * per 128-column block (fp32 fix-up on the device); inf / NaN propagate.  Accuracy: |err| <= 2^-21 sum |a b| per output as long
- * as every contributing operand entry lies within 2^26 of the magnitude its row / column was scaled to; smaller entries carry an
- * absolute error of 2^-36 of that magnitude (negligible norm-wise).  For dW this is GUARDED: a column of dY whose non-zero
- * entries span more than 2^26 sends the whole dW to the fp32 kernel (device-side decision, found by the randomized test: such
- * entries matter where X is zero at the large entries' items); for dX (rows of dY, columns of W) it is not.
+ * db or without) and dX may each be NULL (not wanted).  inf / NaN give non-finite results where F.linear's backward has them.
+ *   dW  both operands as THREE bf16 parts (x = b1 + b2 + b3 exactly to 2^-24; bf16 has fp32's exponent range: no scales, no
+ *       guard, no second launch), six products per 16 items in one fp32 accumulator set:
+ *       |err| <= 2^-22 sum |dy x| per output + fp32 accumulation, for any magnitudes; entries below 2^-110 are carried to an
+ *       absolute 2^-133 (bf16's smallest denormal) instead of a relative 2^-24.
+ *       (The first form used two fp16 halves and one power-of-two scale per column of dY behind a range guard: the gradient
+ *       columns of a real batch span more than any one scale holds and the guard's fp32 fix-up ran on most training steps.)
+ *   dX  two fp16 halves of dY and W, three products, the operands brought into fp16's range by exact power-of-two scales (per
+ *       row of dY, in registers; per column of W): |err| <= 2^-21 sum |dy w| per output as long as the entries of a dY ROW / a
+ *       W COLUMN lie within 2^28 of that row's / column's maximum; smaller entries carry an absolute error of 2^-36 of the
+ *       maximum's power of two (negligible against the sum unless the large entries' partners are exactly zero).  Stated, not
+ *       guarded.
  * out == 64 and F % 128 == 0 run these kernels, every other shape is handed to mmrec_linear_bwd_w_f32 / mmrec_linear_bwd_x_f32.
  * Deterministic (no float atomics).
  * workspace: mmrec_linear_bwd_split_workspace_bytes (>= mmrec_linear_workspace_bytes). */

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
                                                            int n_chunk, int ldg, const int* __restrict__ redo) {
     __shared__ __attribute__((aligned(16))) float Gs[BW_BK][64];
     __shared__ __attribute__((aligned(16))) float Xs[BW_BK][BW_BF];
-    if (redo && !(redo[blockIdx.x] | redo[gridDim.x])) return;      // fix-up launch of mmrec_linear_bwd_split_f32: flagged 128-column blocks only (redo[last]: all of them)
+    if (redo && !(redo[blockIdx.x] | redo[gridDim.x])) return;      // (a flag-driven partial launch: unused since the dW path went to bf16 x 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * BW_BF;
     const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
@@ -631,18 +631,13 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restri
 // =====================================================================================================================
 // Projection BACKWARD on the 16-bit matrix cores with split operands (ABI 11: mmrec_linear_bwd_split_f32).
 // dW = dY^T X and dX = dY W are fp32-MFMA bound in the kernels above (2 n F 64 FLOP each at the 1/16-rate fp32 matrix pipe:
-// 23.5 us at Amazon-Baby size at the nominal clock, 40 us measured) although each only has to stream X once (dW) or write dX once.
-// Same split as the forward (x = hi + 2^-11 lo' in fp16, three fp16 products, fp32 accumulators, error <= 2^-21 |a b| per
-// product), with the operands brought into fp16's range by exact power-of-two scales that are undone in the epilogue:
-//   * dY (gradients: 1e-3 ... 1e-12) -- dW: one scale per OUTPUT COLUMN o, from the column maxima of dY (bwd_dy_colmax_kernel),
-//     applied when dY is written transposed + split into the tile layout the MFMA's A operand wants (bwd_dy_tsplit_kernel, which
-//     also produces the bias gradient's partial sums in fp32); dX: one scale per ROW of dY, in registers (K = 64: a lane pair
-//     holds the whole row);
-//   * W -- dX: one scale per COLUMN f (the 64 weights of one feature), applied when W is written transposed + split
-//     (bwd_wt_split_kernel);
-//   * X -- dW: unscaled, like the forward, and with the forward's guard: a 128-column block with a non-finite result or a column
-//     whose largest |x| is below 2^-10 (not 0) is recomputed by the fp32 kernel (redo flags, no host synchronisation).
-// Inf / NaN anywhere give inf / NaN results as F.linear's backward does (scales fall back to 1).
+// 23.5 us at Amazon-Baby size at the nominal clock, 36 us measured) although each only has to stream X once (dW) or write dX once.
+//   * dW (contraction over the ITEMS: gradients of one batch span 40 binades along it, features are what they are): three-way
+//     bf16 split of both operands, six products per 16 k, no scales, no guards -- linear_bwd_w_bf16x3_kernel;
+//   * dX (contraction over the 64 outputs): the forward's two fp16 halves, three products, with the operands brought into fp16's
+//     range by exact power-of-two scales that are undone in the epilogue: one per ROW of dY, in registers (K = 64: a lane pair
+//     holds the whole row), and one per COLUMN f of W, applied when W is written transposed + split (bwd_wt_split_kernel).
+// Inf / NaN anywhere give non-finite results as F.linear's backward does.
 // =====================================================================================================================
 __device__ __forceinline__ void split8(const float (&x)[8], g_half8& hi, g_half8& lo) {
 #pragma unroll
@@ -666,15 +661,9 @@ __device__ __forceinline__ void pow2_scale(float mx, int target, float& sc, floa
 
 // W [64][F] -> Wt_sp: row f = 256 B = 16 chunks of 16 B: chunks 0..7 the fp16 hi halves of cs_f w[8c .. 8c + 7][f], chunks 8..15
 // the lo' halves; chunk c is stored at position c ^ (f & 15) (the LDS-DMA copies a 128-row tile linearly; the swizzle makes the
-// 16-B fragment reads of 32 consecutive rows conflict free).  wcs_inv[f] = 1 / cs_f.  Block 0 also clears the cells K1 raises
-// (dY column maxima) and the redo flags of the dW guard.
+// 16-B fragment reads of 32 consecutive rows conflict free).  wcs_inv[f] = 1 / cs_f.
 __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wt_sp,
-                                                           float* __restrict__ wcs_inv, unsigned* __restrict__ cells,
-                                                           int* __restrict__ redo, int n_redo) {
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < 64) { cells[threadIdx.x] = 0u; cells[64 + threadIdx.x] = 0x7f800000u; }      // column maxima / minima of |dY|
-        for (int j = threadIdx.x; j < n_redo; j += 256) redo[j] = 0;
-    }
+                                                           float* __restrict__ wcs_inv) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
     float w[64], mx = 0.f;
@@ -699,196 +688,151 @@ __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restri
     }
 }
 
-// cells[o] = max_i |dY[i][o]|, cells[64 + o] = min over the NON-ZERO entries, both as bit patterns of non-negative floats
-// (monotone as unsigned; a NaN's pattern is larger than inf's, so non-finite entries surface as ex == 255 in pow2_scale).
-// Grid-stride over rows, one atomicMax + one atomicMin per column and block.  The minimum is the dW path's range guard: one scale
-// per column keeps 22 bits only for entries within 2^26 of the column's maximum (bwd_dy_tsplit_kernel decides).
-__global__ __launch_bounds__(256) void bwd_dy_colmax_kernel(const float* __restrict__ dY, int n, unsigned* __restrict__ cells) {
-    __shared__ unsigned red[16][64], redn[16][64];
-    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
-    unsigned m[4] = {0u, 0u, 0u, 0u}, mn[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u};
-    for (int row = blockIdx.x * 16 + r0; row < n; row += gridDim.x * 16) {       // (grid: <= 256 workgroups, see the launch)
-        const float4 v = reinterpret_cast<const float4*>(dY)[(size_t)row * 16 + c4];
-        const unsigned u[4] = {__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu,
-                               __float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu};
+// dW partial[o][f] over an item chunk on v_mfma_f32_32x32x16_bf16 with THREE-WAY split operands: every fp32 number is
+// b1 + b2 + b3 with b1 = bf16(x), b2 = bf16(x - b1), b3 = bf16(x - b1 - b2) -- 24 significand bits in three pieces that each
+// carry fp32's 8-bit exponent, so there is nothing to scale and nothing to guard: gradients of 1e-30 next to gradients of 1e-3
+// (a batch's BPR coefficients span 40 binades once pairs separate: measured on the Amazon-Sports-shaped FREEDOM step), features
+// of any magnitude, inf / NaN (non-finite in, non-finite out; an inf may come out as NaN: inf - bf16(inf) is NaN) all take the
+// same path.  x y = b1 c1 + (b1 c2 + b2 c1) + (b2 c2 + b1 c3 + b3 c1) + O(2^-24 |x y|): six products per 16 k (the fp16 form of
+// the forward takes three, eight fp32 MFMAs take 16 x the time), one fp32 accumulator set, smallest products first.
+// The FIRST form of this kernel used the forward's two fp16 halves with one power-of-two scale per column of dY and a range
+// guard; real gradient columns leave any single scale's range within an epoch (guard at 2^26: fired on most steps, at 2^30: on
+// 16 % of the steps of epoch 0 and rising), each time sending dW to a slow fix-up -- profiles/r05_run_configs.log.
+// Structure: linear_bwd_w_dma_kernel's (both operand tiles by LDS-DMA in their natural item-major layout, 3-stage ring, fused
+// bias-gradient partials); X is split in registers by the wave that multiplies it, dY -- wanted by all four waves -- once per
+// workgroup into LDS fragments one tile ahead (the split is ~6 VALU per element; with dY split per wave the loop had 990 VALU
+// against 72 MFMAs per 96 items and the VALU, not the X stream, set its time).
+typedef __attribute__((ext_vector_type(8))) __bf16 g_bf8;
+__device__ __forceinline__ void split3(const float (&x)[8], g_bf8& p1, g_bf8& p2, g_bf8& p3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            m[e] = max(m[e], u[e]);
-            mn[e] = min(mn[e], u[e] ? u[e] : 0x7f800000u);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { red[r0][4 * c4 + e] = m[e]; redn[r0][4 * c4 + e] = mn[e]; }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        unsigned t = 0u, tn = 0x7f800000u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { t = max(t, red[k][threadIdx.x]); tn = min(tn, redn[k][threadIdx.x]); }
-        if (t) atomicMax(cells + threadIdx.x, t);
-        if (tn != 0x7f800000u) atomicMin(cells + 64 + threadIdx.x, tn);
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 b1 = (__bf16)x[e];
+        const float r1 = x[e] - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        p1[e] = b1;
+        p2[e] = b2;
+        p3[e] = (__bf16)(r1 - (float)b2);
     }
 }
 
-// One workgroup per BWD_TB consecutive 32-item blocks (2 ... 64: at most ~1024 workgroups and db partials); per block b: dY[32 b .. +31][0..63] -> the 8 KB tile the dW kernel's
-// LDS-DMA copies linearly: row o = 128 B = 8 chunks of 16 B: chunks 0..3 the hi halves of S_o dY[32 b + 8 q .. + 7][o]
-// (q = chunk), chunks 4..7 the lo' halves; chunk c at position c ^ ((o >> 1) & 7) (the forward's W-tile swizzle).  S_o brings
-// column o's maximum to [2^14, 2^15).  dbpart[workgroup][o] = sum of the workgroup's items of column o, in fp32, items in order
-// (bias gradient; db_reduce_kernel sums the workgroups' partials in order).
-__global__ __launch_bounds__(256) void bwd_dy_tsplit_kernel(const float* __restrict__ dY, int n, const unsigned* __restrict__ cells,
-                                                            float* __restrict__ dYt_sp, float* __restrict__ dbpart, int nblk,
-                                                            int BWD_TB, int* __restrict__ redo_all) {
-    __shared__ __attribute__((aligned(16))) float Gs[32][64 + 1];
-    const int tid = threadIdx.x;
-    // range guard of the dW path: a column whose non-zero entries span more than 2^26 (exponent fields 26 apart) cannot keep
-    // fp32's relative accuracy for its small entries under ONE scale -- they matter where X is zero at the large ones' items --
-    // so the whole dW is then left to the fp32 fix-up kernel (redo_all; gradients of one batch span a few decades, not eight)
-    if (blockIdx.x == 0 && tid < 64) {
-        const unsigned mx = cells[tid], mn = cells[64 + tid];
-        if (mx < 0x7f800000u && mn < mx && (mx >> 23) - (mn >> 23) > 26u) *redo_all = 1;
-    }
-    const int o = tid >> 2, q = tid & 3;
-    float sc, inv;
-    pow2_scale(__uint_as_float(cells[o]), 14, sc, inv);
-    const int sw = (o >> 1) & 7;
-    float dbacc = 0.f;
-    for (int b = blockIdx.x * BWD_TB; b < min(nblk, (blockIdx.x + 1) * BWD_TB); ++b) {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int e = tid + 256 * p, r = e >> 4, c = (e & 15) * 4;
-            const int item = 32 * b + r;
-            const float4 v = item < n ? reinterpret_cast<const float4*>(dY)[(size_t)item * 16 + (e & 15)] : f4_zero();
-            Gs[r][c] = v.x; Gs[r][c + 1] = v.y; Gs[r][c + 2] = v.z; Gs[r][c + 3] = v.w;
-        }
-        __syncthreads();
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = Gs[8 * q + e][o] * sc;
-        g_half8 hi, lo;
-        split8(x, hi, lo);
-        float* row = dYt_sp + (size_t)b * 2048 + o * 32;
-        *reinterpret_cast<g_half8*>(row + ((q ^ sw) << 2)) = hi;
-        *reinterpret_cast<g_half8*>(row + (((4 + q) ^ sw) << 2)) = lo;
-        if (dbpart && tid < 64) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) dbacc += Gs[k][tid];
-        }
-    }
-    if (dbpart && tid < 64) dbpart[(size_t)blockIdx.x * 64 + tid] = dbacc;
-}
-
-// dW partial[o][f] over an item chunk on v_mfma_f32_32x32x16_f16: D[i = o][j = f], contraction over items.  grid (F / 128, nsplit);
-// wave w owns the 32 columns f0 + 32 w .. and all 64 outputs.  A fragments come ready from the pre-split dY tile (one 16-B LDS
-// read per 8 items), B fragments are 8 lane-consecutive ds_read_b32 of the fp32 X tile, split in registers.  Same 3-stage LDS-DMA
-// ring as linear_bwd_w_dma_kernel (X tile natural [item][f], G tile 8 KB linear).  Needs n_chunk * F * 4 < 2^31.
+#ifndef MMREC_BWD_W_STAGES
+#define MMREC_BWD_W_STAGES 3     // X tiles in the LDS ring (S - 1 in flight per workgroup); 4, 5, 6 measured 1 ... 2 us slower at Amazon-Baby size: profiles/r05_linear_bwd_w_bf16x3_ab.log
+#endif
 template <bool NT>     // NT: X does not fit the Infinity Cache and is read once per call: streamed non-temporal (as in the forward)
-__global__ __launch_bounds__(256, 2) void bwd_w_f16x3_kernel(const float* __restrict__ dYt_sp, const float* __restrict__ X,
-                                                             float* __restrict__ part, int* __restrict__ redo,
-                                                             const unsigned* __restrict__ cells, int n, int F, int n_chunk) {
-    __shared__ __attribute__((aligned(1024))) float G0[2048], G1[2048], G2[2048];
-    __shared__ __attribute__((aligned(1024))) float X0[BW_BK * BW_BF], X1[BW_BK * BW_BF], X2[BW_BK * BW_BF];
-    __shared__ float s_inv[64];
+__global__ __launch_bounds__(256) void linear_bwd_w_bf16x3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                  float* __restrict__ part, float* __restrict__ dbpart, int n, int F,
+                                                                  int n_chunk) {
+    constexpr int S = MMREC_BWD_W_STAGES;
+    __shared__ __attribute__((aligned(1024))) float Xr[S][BW_BK * BW_BF];     // X tiles [item][f], S-stage ring
+    __shared__ __attribute__((aligned(1024))) float Gq[S - 1][BW_BK * 64];    // dY tiles [item][o] as they arrive
+    __shared__ __attribute__((aligned(1024))) g_bf8 Asp[2][12 * 64];          // their split MFMA fragments [2 kstep + otile][part][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f0 = blockIdx.x * BW_BF;
     const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
     const int rows = ne - nb;
-    if (tid < 64) {
-        float sc, inv;
-        pow2_scale(__uint_as_float(cells[tid]), 14, sc, inv);
-        s_inv[tid] = inv;
-    }
-    const int T = (rows + BW_BK - 1) / BW_BK;
     const i32x4 rx = raw_rsrc(X + (size_t)nb * F + f0, (unsigned)rows * (unsigned)F * 4u - (unsigned)f0 * 4u);
-    const i32x4 rg = raw_rsrc(dYt_sp + (size_t)(nb / BW_BK) * 2048, (unsigned)T * 8192u);
-    int vx[4];
+    const i32x4 rg = raw_rsrc(dY + (size_t)nb * 64, (unsigned)rows * 256u);
+    int vx[4], vg[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) vx[j] = (2 * (4 * wave + j) + (lane >> 5)) * F * 4 + (lane & 31) * 16;
-    auto issue = [&](float* gs, float* xs, int t) {
-        const int sx = t * BW_BK * F * 4, sg = t * 8192;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16<NT>(rx, lds_addr(xs + (4 * wave + j) * 256), vx[j], sx);
+    for (int j = 0; j < 2; ++j) vg[j] = (4 * (2 * wave + j) + (lane >> 4)) * 256 + (lane & 15) * 16;
+    auto issue = [&](int t, int gb, int xb) {      // the dY tile FIRST: it is wanted one step before its X tile
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds_dma16<false>(rg, lds_addr(gs + (2 * wave + j) * 256), (2 * wave + j) * 1024 + lane * 16, sg);
+        for (int j = 0; j < 2; ++j) lds_dma16<false>(rg, lds_addr(&Gq[gb][(2 * wave + j) * 256]), vg[j], t * BW_BK * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16<NT>(rx, lds_addr(&Xr[xb][(4 * wave + j) * 256]), vx[j], t * BW_BK * F * 4);
     };
     const int i = lane & 31, h = lane >> 5;
-    f32x16 hh0 = {0}, hh1 = {0}, cx0 = {0}, cx1 = {0};
-    float xmax = 0.f;
-    const int sw0 = (i >> 1) & 7, sw1 = ((32 + i) >> 1) & 7;
-    auto compute = [&](const float* gs, const float* xs) {
+    const bool do_db = dbpart && blockIdx.x == 0 && tid < 64;
+    f32x16 acc0 = {0}, acc1 = {0};
+    float dbacc = 0.f;
+    // each dY element is split ONCE per workgroup: wave w owns fragment (kstep = w >> 1, otile = w & 1) of the tile
+    auto split_g = [&](int gb, int ab) {
+        const float* gq = Gq[gb];
+        if (do_db) {
+#pragma unroll
+            for (int k = 0; k < BW_BK; ++k) dbacc += gq[k * 64 + tid];
+        }
+        const float* gr = gq + (16 * (wave >> 1) + 8 * h) * 64 + 32 * (wave & 1) + i;
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = gr[e * 64];
+        g_bf8 a1, a2, a3;
+        split3(gv, a1, a2, a3);
+        g_bf8* dst = &Asp[ab][wave * 3 * 64 + lane];
+        dst[0] = a1;
+        dst[64] = a2;
+        dst[128] = a3;
+    };
+    auto compute = [&](int ab, int xb) {
+        const float* xs = Xr[xb];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const g_half8 ah0 = *reinterpret_cast<const g_half8*>(gs + i * 32 + (((2 * st + h) ^ sw0) << 2));
-            const g_half8 al0 = *reinterpret_cast<const g_half8*>(gs + i * 32 + (((4 + 2 * st + h) ^ sw0) << 2));
-            const g_half8 ah1 = *reinterpret_cast<const g_half8*>(gs + (32 + i) * 32 + (((2 * st + h) ^ sw1) << 2));
-            const g_half8 al1 = *reinterpret_cast<const g_half8*>(gs + (32 + i) * 32 + (((4 + 2 * st + h) ^ sw1) << 2));
-            float xv[8];
+            const float* xr = xs + (16 * st + 8 * h) * BW_BF + 32 * wave + i;
+            g_bf8 b1, b2, b3;
+            {
+                float xv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = xs[(16 * st + 8 * h + e) * BW_BF + 32 * wave + i];
-            g_half8 bh, bl;
-            split8(xv, bh, bl);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) xmax = fmaxf(fmaxf(xmax, fabsf(xv[e])), fabsf(xv[e + 1]));
-            hh0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, hh0, 0, 0, 0);
-            hh1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, hh1, 0, 0, 0);
-            cx0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, cx0, 0, 0, 0);
-            cx1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, cx1, 0, 0, 0);
-            cx0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh, cx0, 0, 0, 0);
-            cx1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, cx1, 0, 0, 0);
+                for (int e = 0; e < 8; ++e) xv[e] = xr[e * BW_BF];
+                split3(xv, b1, b2, b3);
+            }
+            {   // output tile 0 (o = i)
+                const g_bf8* ap = &Asp[ab][(2 * st) * 3 * 64 + lane];
+                const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc0, 0, 0, 0);
+            }
+            {   // output tile 1 (o = 32 + i)
+                const g_bf8* ap = &Asp[ab][(2 * st + 1) * 3 * 64 + lane];
+                const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128];
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc1, 0, 0, 0);
+            }
         }
     };
-    auto step = [&](const float* gc, const float* xc, float* gn, float* xn, int t) {
-        if (t + 1 < T) MMREC_WAIT_VM(6); else MMREC_WAIT_VM(0);
+    // vmcnt queue: [G(0) X(0)] [G(1) X(1)] ... (2 + 4 copies per tile and wave), S - 1 tiles ahead; tiles past the end are
+    // issued all the same (out of the descriptors' range: zero fill, no memory traffic) so that one count holds in every step:
+    // step t wants X(t) and G(t + 1), i.e. at most X(t + 1) and the S - 3 groups behind it still in flight.
+    const int T = (rows + BW_BK - 1) / BW_BK;
+    if (T > 0) {
+#pragma unroll
+        for (int u = 0; u < S - 1; ++u) issue(u, u, u);
+        MMREC_WAIT_VM(4 + 6 * (S - 2));
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < T) issue(gn, xn, t + 2);
-        compute(gc, xc);
-    };
-    if (T > 0) issue(G0, X0, 0);
-    if (T > 1) issue(G1, X1, 1);
-    for (int t = 0; t < T;) {
-        step(G0, X0, G2, X2, t); if (++t >= T) break;
-        step(G1, X1, G0, X0, t); if (++t >= T) break;
-        step(G2, X2, G1, X1, t); ++t;
+        split_g(0, 0);
     }
-    __syncthreads();                                   // s_inv (T == 0: nothing else has synchronised yet)
+    int xb = 0, gb = 0;                                          // t % S, t % (S - 1)
+    for (int t = 0; t < T; ++t) {
+        MMREC_WAIT_VM(4 + 6 * (S - 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment of tile t is in Asp
+        __builtin_amdgcn_s_barrier();
+        issue(t + S - 1, gb, xb == 0 ? S - 1 : xb - 1);          // into the buffers of tile t - 1 (X) and of tile t's dY (split in step t - 1)
+        const int gn = gb == S - 2 ? 0 : gb + 1;
+        if (t + 1 < T) split_g(gn, (t + 1) & 1);
+        compute(t & 1, xb);
+        xb = xb == S - 1 ? 0 : xb + 1;
+        gb = gn;
+    }
+    MMREC_WAIT_VM(0);      // (the zero-fill copies of the tiles past the end)
+    if (do_db) dbpart[blockIdx.y * 64 + tid] = dbacc;
     float* dst = part + (size_t)blockIdx.y * 64 * F;
     const int f = f0 + wave * 32 + i;
-    bool bad = false;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = d_row(r, lane);
-        const float y0 = fmaf(cx0[r], 1.f / 2048.f, hh0[r]) * s_inv[o], y1 = fmaf(cx1[r], 1.f / 2048.f, hh1[r]) * s_inv[32 + o];
-        dst[(size_t)o * F + f] = y0;
-        dst[(size_t)(32 + o) * F + f] = y1;
-        bad |= !(fabsf(y0) < __builtin_inff()) | !(fabsf(y1) < __builtin_inff());
+        dst[(size_t)o * F + f] = acc0[r];
+        dst[(size_t)(32 + o) * F + f] = acc1[r];
     }
-    // the two lane halves hold the two item halves of column f.  The guard is taken per ITEM CHUNK (conservative: a column that
-    // is tiny, and not zero, throughout one workgroup's items is recomputed in fp32 even if other chunks hold ordinary values)
-    xmax = fmaxf(xmax, __shfl_xor(xmax, 32));
-    bad |= xmax > 0.f && xmax < SPLIT_ROW_MIN;
-    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) redo[blockIdx.x] = 1;
-}
-
-// dW[o][f] = sum_s part[s][o][f] in slab order (four chains, fixed combination: deterministic); a non-finite sum flags its
-// 128-column block for the fp32 fix-up
-__global__ __launch_bounds__(256) void bwd_w_reduce_kernel(const float* __restrict__ part, int nslab, int F, float* __restrict__ dW,
-                                                           int* __restrict__ redo) {
-    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x, slab = (size_t)64 * F;
-    if (i4 * 4 >= slab) return;
-    float4 t0 = f4_zero(), t1 = f4_zero(), t2 = f4_zero(), t3 = f4_zero();
-    int s = 0;
-    for (; s + 3 < nslab; s += 4) {
-        t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)(s + 0) * slab)[i4]);
-        t1 = f4_add(t1, reinterpret_cast<const float4*>(part + (size_t)(s + 1) * slab)[i4]);
-        t2 = f4_add(t2, reinterpret_cast<const float4*>(part + (size_t)(s + 2) * slab)[i4]);
-        t3 = f4_add(t3, reinterpret_cast<const float4*>(part + (size_t)(s + 3) * slab)[i4]);
-    }
-    for (; s < nslab; ++s) t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)s * slab)[i4]);
-    const float4 t = f4_add(f4_add(t0, t1), f4_add(t2, t3));
-    reinterpret_cast<float4*>(dW)[i4] = t;
-    const float inf = __builtin_inff();
-    if (!(fabsf(t.x) < inf) | !(fabsf(t.y) < inf) | !(fabsf(t.z) < inf) | !(fabsf(t.w) < inf))
-        redo[(int)((i4 * 4) % (size_t)F) / BW_BF] = 1;
 }
 
 // dX[n, F] = dY[n, 64] W[64, F] on v_mfma_f32_32x32x16_f16, the streaming form of gemm64_stream_kernel (mfma_stream.h): a
@@ -1133,13 +1077,12 @@ extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const 
 }
 
 // ---- ABI 11: the projection's backward on the 16-bit matrix cores (see the kernels' comment block) ----------------------------
-// Workspace layout (mmrec_linear_bwd_split_workspace_bytes): [W^T split: F x 256 B][wcs_inv: F + 256 floats][cells: 64 column maxima + 64 minima, u32]
-// [redo: F / 128 + 1 ints][dY^T split tiles: ceil(n / 32) x 8 KB][db partials: <= 1024 x 64 floats][dW slabs: nsplit > 1 ?
-// nsplit x 64 x F floats]; never smaller than what the fp32 entry points need (shapes they serve).
+// Workspace layout (mmrec_linear_bwd_split_workspace_bytes): [W^T split: F x 256 B][wcs_inv: F + 256 floats][db partials:
+// nsplit x 64 floats][dW slabs: nsplit > 1 ? nsplit x 64 x F floats]; never smaller than what the fp32 entry points need.
 namespace {
 struct BwdSplitWs {
-    size_t wt, wcs, cells, redo, dyt, dbp, slabs, total;
-    int nsplit, chunk, nblk, ndb, tb;
+    size_t wt, wcs, dbp, slabs, total;
+    int nsplit, chunk;
 };
 inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 inline BwdSplitWs bwd_split_ws(int n, int F) {
@@ -1149,22 +1092,14 @@ inline BwdSplitWs bwd_split_ws(int n, int F) {
     w.chunk = ceil_div(ceil_div(n, MMREC_BWD_W_SPLIT), BW_BK) * BW_BK; w.nsplit = ceil_div(n, w.chunk);
 #endif
     // LDS-DMA scalar offsets of the dW kernel: a workgroup's item chunk must stay below 2^31 bytes of X
-    while ((size_t)w.chunk * F * 4 >= ((size_t)1 << 31)) {
+    while ((size_t)(w.chunk + 8 * BW_BK) * F * 4 >= ((size_t)1 << 31)) {      // (+ the tiles issued past the end)
         w.chunk = ceil_div(w.chunk / 2, BW_BK) * BW_BK;
         w.nsplit = ceil_div(n, w.chunk);
     }
-    w.nblk = ceil_div(n, BW_BK);
     size_t off = 0;
     w.wt = off; off += al256((size_t)F * 256);
     w.wcs = off; off += al256(((size_t)F + 256) * 4);
-    w.cells = off; off += 512;
-    w.redo = off; off += al256(((size_t)F / BW_BF + 1) * 4);
-    w.dyt = off; off += al256((size_t)w.nblk * 8192);
-    w.tb = w.nblk / 512;
-    if (w.tb < 2) w.tb = 2;
-    if (w.tb > 64) w.tb = 64;
-    w.ndb = ceil_div(w.nblk, w.tb);
-    w.dbp = off; off += al256((size_t)w.ndb * 64 * 4);
+    w.dbp = off; off += al256((size_t)w.nsplit * 64 * 4);
     w.slabs = off; off += al256(w.nsplit > 1 ? (size_t)w.nsplit * 64 * F * 4 : 0);
     w.total = off;
     return w;
@@ -1185,8 +1120,8 @@ extern "C" size_t mmrec_linear_bwd_split_workspace_bytes(int32_t n, int32_t F, i
 
 // dW [64, F] = dY^T X, db [64] = column sums of dY, dX [n, F] = dY W in ONE call (any of dW+db / dX may be NULL: not wanted).
 // out == 64 and F % 128 == 0 run the split-operand kernels; other shapes are handed to mmrec_linear_bwd_w_f32 /
-// mmrec_linear_bwd_x_f32 (same workspace).  Results: fp32-accurate (error <= 2^-21 of sum |a b| per output, operands scaled
-// into fp16's range by exact powers of two; X columns outside the split's domain are recomputed in fp32 on the device).
+// mmrec_linear_bwd_x_f32 (same workspace).  Results: fp32-accurate (dW: error <= 2^-23 of sum |a b| per output + fp32
+// accumulation, any magnitudes; dX: 2^-21 with the operands scaled into fp16's range by exact powers of two).
 extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const float* W, float* dW, float* db, float* dX,
                                           int32_t n, int32_t F, int32_t out, void* workspace, mmrec_stream_t stream) {
     if (n < 0 || F <= 0 || out <= 0) return MMREC_ERR_BAD_ARG;
@@ -1203,44 +1138,26 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     char* base = static_cast<char*>(workspace);
     float* Wt_sp = reinterpret_cast<float*>(base + w.wt);
     float* wcs_inv = reinterpret_cast<float*>(base + w.wcs);
-    unsigned* cells = reinterpret_cast<unsigned*>(base + w.cells);
-    int* redo = reinterpret_cast<int*>(base + w.redo);
-    float* dYt = reinterpret_cast<float*>(base + w.dyt);
     float* dbp = reinterpret_cast<float*>(base + w.dbp);
     float* slabs = reinterpret_cast<float*>(base + w.slabs);
     const int ncb = F / BW_BF;
     const bool big = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);      // X / dX larger than the Infinity Cache
-    // (also clears the cells / redo flags the dW path uses; W may be NULL when only dW is wanted: then the kernel only clears)
-    if (dX)
-        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv, cells, redo, ncb + 1);
-    else
-        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr, 0, Wt_sp, wcs_inv, cells, redo, ncb + 1);
     if (dW) {
         float* part = w.nsplit == 1 ? dW : slabs;
-        // (A form in which every dW workgroup scans its own item chunk of dY for the scales and splits dY in registers -- no
-        // column-maxima launch, no transposed split, no dY^T workspace -- was built, passed the same tests and LOST: 34.9 us
-        // against 24.3 + 6.9 + 5.0 us at Amazon-Baby size, forward + backward 114 against 110 us as a hipGraph replay:
-        // profiles/r05_linear_bwd_fused_dw_ab.log; the code is in the history.)
-        int cb = ceil_div(n, 64);                // >= 4 rows per thread-row; every workgroup ends with 64 atomicMax on the 64 cells
-        if (cb > 256) cb = 256;
-        hipLaunchKernelGGL(bwd_dy_colmax_kernel, dim3(cb), dim3(256), 0, s, dY, n, cells);
-        hipLaunchKernelGGL(bwd_dy_tsplit_kernel, dim3(w.ndb), dim3(256), 0, s, dY, n, (const unsigned*)cells, dYt,
-                           db ? dbp : (float*)nullptr, w.nblk, w.tb, redo + ncb);
+        float* dbpart = db ? dbp : (float*)nullptr;
         if (big && (MMREC_BWD_NT & 1))
-            hipLaunchKernelGGL(bwd_w_f16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
-                               (const unsigned*)cells, n, F, w.chunk);
+            hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(256), 0, s, dY, X, part, dbpart, n, F, w.chunk);
         else
-            hipLaunchKernelGGL(bwd_w_f16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(256), 0, s, (const float*)dYt, X, part, redo,
-                               (const unsigned*)cells, n, F, w.chunk);
-        if (w.nsplit > 1)
-            hipLaunchKernelGGL(bwd_w_reduce_kernel, dim3((unsigned)(((size_t)64 * F / 4 + 255) / 256)), dim3(256), 0, s,
-                               (const float*)slabs, w.nsplit, F, dW, redo);
-        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)dbp, w.ndb, db);
-        // fix-up: the fp32 kernel over the flagged 128-column blocks (the others return at once), all items per workgroup
-        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(ncb, 1), dim3(256), 0, s, dY, X, dW, (float*)nullptr, n, F,
-                           ceil_div(n, BW_BK) * BW_BK, 64, (const int*)redo);
+            hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(256), 0, s, dY, X, part, dbpart, n, F, w.chunk);
+        if (w.nsplit > 1) {
+            const size_t elems = (size_t)64 * F;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, (const float*)slabs,
+                               w.nsplit, elems, (const float*)nullptr, dW);
+        }
+        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)dbp, w.nsplit, db);
     }
     if (dX) {
+        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv);
         const int rt = ceil_div(n, 128), nft = F / 128;
         int ftiles = 8;
         while (ftiles > 1 && (long)rt * ceil_div(nft, ftiles) < 192) ftiles >>= 1;

@@ -899,10 +899,11 @@ def test_linear_split_guard_is_capture_safe(ops, dev):
 @pytest.mark.parametrize("n,F", [(7050, 4096), (40_000, 4096), (513, 4480), (7050, 384), (2048, 4096)])
 def test_linear_split_backward_is_as_accurate_as_the_fp32_kernels(ops, dev, n, F):
     """mmrec_linear_bwd_split_f32 (ABI 11; the default backward with hip_ops.LINEAR_F16X3): dW = dY^T X, db, dX = dY W on the 16-bit
-    matrix cores with split, power-of-two-scaled operands, against float64, next to the fp32-MFMA kernels.  Gradients of
-    realistic and of hostile magnitude: rows of dY spread over 1e-2 ... 1e-12 (most rows exactly zero: items outside the batch),
-    one output column of dY 1e-8 of the others, feature weights (columns of W) of 1e-8, a feature (column of X) of 1e-7 and one
-    of 1e5 (both leave the split's domain for X: the guard's fp32 fix-up), errors measured against sum |a b| of each output."""
+    matrix cores with split operands (dW: three bf16 parts; dX: two fp16 halves, power-of-two scaled), against float64, next to
+    the fp32-MFMA kernels.  Gradients of realistic and of hostile magnitude: rows of dY spread over 1e-2 ... 1e-12 (most rows
+    exactly zero: items outside the batch), one output column of dY 1e-8 of the others, feature weights (columns of W) of 1e-8, a
+    feature (column of X) of 1e-7 and one of 1e5 (outside what fp16 halves of X could hold: dW's parts carry fp32's exponent),
+    errors measured against sum |a b| of each output."""
     g = torch.Generator().manual_seed(n + F)
     X = torch.relu(torch.randn(n, F, generator=g))
     X[:, 5] *= 1e-7
@@ -946,12 +947,14 @@ def test_linear_split_backward_is_as_accurate_as_the_fp32_kernels(ops, dev, n, F
 
 def test_linear_split_backward_nonfinite_and_extremes(ops, dev):
     """inf / NaN gradients propagate through the split backward as through F.linear's (same pattern of non-finite outputs);
-    gradients of 1e30 and 1e-38 magnitude (scaled by exact powers of two) keep fp32's relative accuracy."""
+    gradients of 1e30 and 1e-31 magnitude keep fp32's relative accuracy (dX: rows scaled by exact powers of two; dW: the three
+    bf16 parts carry fp32's exponent range).  Below 2^-110 (7.7e-34) the LOW parts of an entry fall under bf16's smallest
+    denormal (2^-133): the entry is then carried to an absolute 2^-133 instead of a relative 2^-24 ('floor')."""
     g = torch.Generator().manual_seed(3)
     n, F = 700, 512
     X = torch.relu(torch.randn(n, F, generator=g))
     W = torch.randn(64, F, generator=g) / F ** 0.5
-    for mod in ("nan", "inf", "huge", "tiny"):
+    for mod in ("nan", "inf", "huge", "tiny", "floor"):
         dY = torch.randn(n, 64, generator=g) * 1e-3
         if mod == "nan":
             dY[17, 3] = float("nan")
@@ -959,6 +962,8 @@ def test_linear_split_backward_nonfinite_and_extremes(ops, dev):
             dY[17, 3] = float("inf")
         elif mod == "huge":
             dY *= 1e33
+        elif mod == "tiny":
+            dY *= 1e-28
         else:
             dY *= 1e-33
         Xd, Wd = X.to(dev).requires_grad_(), W.to(dev).requires_grad_()
@@ -973,13 +978,14 @@ def test_linear_split_backward_nonfinite_and_extremes(ops, dev):
         else:
             r64W, r64X = dY.double().t() @ X.double(), dY.double() @ W.double()
             sW, sX = dY.double().abs().t() @ X.double().abs(), dY.double().abs() @ W.double().abs()
-            assert float(((dW.double() - r64W).abs() / sW).max()) <= 1e-6
-            assert float(((dX.double() - r64X).abs() / sX).max()) <= 1e-6
+            floor = 2.0 ** -132 * X.double().abs().sum(0)[None, :] if mod == "floor" else 0.0
+            assert bool(((dW.double() - r64W).abs() <= 1e-6 * sW + floor).all()), mod
+            assert float(((dX.double() - r64X).abs() / sX).max()) <= 1e-6, mod
 
 
 def test_linear_split_backward_is_capture_safe_and_deterministic(ops, dev):
-    """the backward's scales and guard live on the device: capturable, replayable on changed gradients, and two runs agree bit
-    for bit (no float atomics: the column maxima go through integer atomicMax, the sums through fixed-order reductions)."""
+    """the backward's scales live on the device: capturable, replayable on changed gradients, and two runs agree bit for bit (no
+    float atomics: slabs and bias-gradient partials are summed in fixed order)."""
     g = torch.Generator().manual_seed(12)
     X = torch.relu(torch.randn(3000, 4096, generator=g)).to(dev).requires_grad_()
     W = (torch.randn(64, 4096, generator=g) / 64).to(dev).requires_grad_()

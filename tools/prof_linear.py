@@ -57,20 +57,23 @@ def main():
         del X, W, b, G, Xg
 
 
-VARIANTS = {"nt0": 0, "nt1_dw_reads": 1, "nt2_dx_stores": 2, "nt3_both": 3}    # -DMMREC_BWD_NT=<bits> builds of gemm.hip
+VARIANTS = {"nt0": "-DMMREC_BWD_NT=0", "nt1_dw_reads": "-DMMREC_BWD_NT=1", "nt2_dx_stores": "-DMMREC_BWD_NT=2",
+            "nt3_both": "-DMMREC_BWD_NT=3"}          # builds of gemm.hip with extra flags
 
 
-def build_variants():
-    """python tools/prof_linear.py build-variants   (here, no GPU): tools/probe_libs/libmmrec_bwd_<name>.so"""
+def build_variants(specs=()):
+    """python tools/prof_linear.py build-variants [name=-DFLAG[,-DFLAG] ...]   (here, no GPU): tools/probe_libs/libmmrec_bwd_<name>.so
+    (default: the MMREC_BWD_NT set above)"""
+    variants = dict(sp.split("=", 1) for sp in specs) if specs else VARIANTS
     import subprocess
     from mmrec_amd import build as b
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_libs")
     os.makedirs(out, exist_ok=True)
     b.build(verbose=False)
     objs = [os.path.join(b.OBJ, s.replace(".hip", ".o")) for s in b.SOURCES if s != "gemm.hip"]
-    for name, bits in VARIANTS.items():
+    for name, flags in variants.items():
         o = os.path.join(out, "gemm_%s.o" % name)
-        subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DMMREC_BWD_NT=%d" % bits, "-c", os.path.join(b.CSRC, "gemm.hip"), "-o", o])
+        subprocess.check_call([b._hipcc()] + b.FLAGS + flags.split(",") + ["-c", os.path.join(b.CSRC, "gemm.hip"), "-o", o])
         subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(out, "libmmrec_bwd_%s.so" % name)] + objs + [o])
         os.remove(o)
@@ -93,7 +96,7 @@ def run_variants(shapes):
 
 if __name__ == "__main__":
     if sys.argv[1:2] == ["build-variants"]:
-        build_variants()
+        build_variants(sys.argv[2:])
     elif sys.argv[1:2] == ["run-variants"]:
         run_variants(sys.argv[2:])
     else:

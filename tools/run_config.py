@@ -106,6 +106,7 @@ def main():
                                                                "(FREEDOM, BM3 default to the row-lazy exact Adam)")
     ap.add_argument("--deterministic", action="store_true", help="hip_deterministic: position-ordered gradient scatters")
     ap.add_argument("--no-batch-rows", action="store_true", help="FREEDOM: hip_pull_batch_rows False (launches over all rows)")
+    ap.add_argument("--fp32-linear", action="store_true", help="hip_linear_split False: projection forward + backward on the fp32-MFMA kernels")
     args = ap.parse_args()
     cd = dict(device_neg_sampling=args.device_neg_sampling)
     if args.graph_step or args.eager:
@@ -118,6 +119,8 @@ def main():
         cd['hip_deterministic'] = True
     if args.no_batch_rows:
         cd['hip_pull_batch_rows'] = False
+    if args.fp32_linear:
+        cd['hip_linear_split'] = False
     config, train_data, valid_data, test_data, model, _ = setup(args.config, cd, args.epochs)
     from mmrec_amd.common.trainer import Trainer
     trainer = Trainer(config, model)
@@ -136,6 +139,9 @@ def main():
               "(%.0f users/s incl. metrics) | valid recall@20 %.4f ndcg@20 %.4f | test recall@20 %.4f" %
               (args.config, epoch, t1 - t0, len(train_data), (t1 - t0) / len(train_data) * 1e3, loss,
                t2 - t1, n_eval / (t2 - t1), valid["recall@20"], valid["ndcg@20"], test["recall@20"]), flush=True)
+    gs = getattr(trainer, '_graphed', None)
+    print("[%s] training step: %s" % (args.config, "eager (no graphed step)" if gs is None else
+                                      ("hipGraph capture FAILED -> eager" if gs.failed else "hipGraph replay")))
     print("[%s] peak device memory %.2f GB" % (args.config, torch.cuda.max_memory_allocated() / 2 ** 30))
 
 
