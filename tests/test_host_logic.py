@@ -576,3 +576,53 @@ def test_split_operand_projection_domain_rule():
     assert np.nanmax(rel[ok & (rowmax > 0)]) <= 1e-6                         # the test the device suite applies
     assert np.array_equal(got[14], np.zeros(64, f32))
 
+
+
+def _bf16_round(a):
+    """fp32 -> bf16 -> fp32, round to nearest even (what v_cvt_pk_bf16_f32 does), on a float32 array"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_bf16_three_way_split_projection_gradient_claim():
+    """gemm.hip linear_bwd_w_bf16x3_kernel, restated in numpy: x = b1 + b2 + b3 with b1 = bf16(x), b2 = bf16(x - b1),
+    b3 = bf16(x - b1 - b2); dW = sum over items of the six products b_i c_j with i + j <= 4 (the three dropped ones are
+    <= 2^-23 |x y|).  Claims checked: (1) the three parts restore x to 2^-24 relative -- for magnitudes 1e-30 ... 1e30 alike,
+    no scale involved; (2) dW's error against float64 is <= 2^-22 sum |dy x| per output on a gradient column that spans 2^44
+    (the case one power-of-two scale per column cannot hold: the guarded fp16 form's fix-up) with X zero where the large
+    gradients sit; (3) entries below 2^-110 degrade to an absolute 2^-133, not to garbage."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(4096) * 10.0 ** rng.uniform(-30, 30, 4096)).astype(np.float32)
+    b1 = _bf16_round(x)
+    r1 = x - b1
+    b2 = _bf16_round(r1)
+    b3 = _bf16_round(r1 - b2)
+    back = b1.astype(np.float64) + b2.astype(np.float64) + b3.astype(np.float64)
+    assert np.max(np.abs(back - x.astype(np.float64)) / np.abs(x.astype(np.float64))) <= 2.0 ** -24
+
+    def split(a):
+        p1 = _bf16_round(a)
+        q = a - p1
+        p2 = _bf16_round(q)
+        return [p.astype(np.float64) for p in (p1, p2, _bf16_round(q - p2))]
+    n, F = 2048, 64
+    e = rng.uniform(-44, 0, (n, 1))
+    dy = (rng.standard_normal((n, 8)) * 2.0 ** e).astype(np.float32)
+    X = np.maximum(rng.standard_normal((n, F)), 0).astype(np.float32)
+    X[e[:, 0] > -38] = 0.0                                           # features only where the gradients are small: those rows ARE the result
+    a, c = split(dy), split(X)
+    got = sum(a[i].T @ c[j] for i in range(3) for j in range(3) if i + j <= 2)
+    ref = dy.astype(np.float64).T @ X.astype(np.float64)
+    mag = np.abs(dy.astype(np.float64)).T @ np.abs(X.astype(np.float64))
+    assert np.max(np.abs(got - ref) / mag) <= 2.0 ** -22
+    # one fp16 scale per column (the form this replaced): the small rows vanish below fp16's denormals
+    sc = 2.0 ** (14 - np.ceil(np.log2(np.abs(dy).max(0))))
+    with np.errstate(under="ignore"):
+        h = (dy * sc).astype(np.float16).astype(np.float64)
+        lo = ((dy * sc - h) * 2048.0).astype(np.float16).astype(np.float64) / 2048.0
+    got16 = ((h + lo) / sc).T @ X.astype(np.float64)
+    assert np.max(np.abs(got16 - ref) / mag) > 1e-4                  # (why that form needed its guard)
+    tiny = (rng.standard_normal(512) * 1e-36).astype(np.float32)
+    t = split(tiny)
+    assert np.max(np.abs(t[0] + t[1] + t[2] - tiny.astype(np.float64))) <= 2.0 ** -133
