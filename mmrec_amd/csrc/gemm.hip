@@ -699,9 +699,8 @@ __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restri
 // guard; real gradient columns leave any single scale's range within an epoch (guard at 2^26: fired on most steps, at 2^30: on
 // 16 % of the steps of epoch 0 and rising), each time sending dW to a slow fix-up -- profiles/r05_run_configs.log.
 // Structure: linear_bwd_w_dma_kernel's (both operand tiles by LDS-DMA in their natural item-major layout, 3-stage ring, fused
-// bias-gradient partials); X is split in registers by the wave that multiplies it, dY -- wanted by all four waves -- once per
-// workgroup into LDS fragments one tile ahead (the split is ~6 VALU per element; with dY split per wave the loop had 990 VALU
-// against 72 MFMAs per 96 items and the VALU, not the X stream, set its time).
+// bias-gradient partials); X is split in registers by the wave that multiplies it, dY -- wanted by every wave -- once per
+// workgroup into LDS fragments one tile ahead (the split is ~6 VALU per element).
 typedef __attribute__((ext_vector_type(8))) __bf16 g_bf8;
 __device__ __forceinline__ void split3(const float (&x)[8], g_bf8& p1, g_bf8& p2, g_bf8& p3) {
 #pragma unroll
@@ -715,11 +714,16 @@ __device__ __forceinline__ void split3(const float (&x)[8], g_bf8& p1, g_bf8& p2
     }
 }
 
+// Eight waves, two per SIMD: wave w multiplies k-step (w >> 2) of every 32-item tile into its own accumulators for the 32 columns
+// (w & 3); the two k-step halves are added through LDS at the end.  (With four waves -- one per SIMD running its LDS reads, ~170
+// VALU and 24 MFMAs per tile back to back -- the kernel took 39.9 us at Amazon-Baby size; with two per SIMD one wave's MFMAs run
+// under the other's split: -3.4 us forward + backward at Baby size, -15 us at Sports size, profiles/r05_linear_bwd_w_bf16x3_ab.log.)
 #ifndef MMREC_BWD_W_STAGES
 #define MMREC_BWD_W_STAGES 3     // X tiles in the LDS ring (S - 1 in flight per workgroup); 4, 5, 6 measured 1 ... 2 us slower at Amazon-Baby size: profiles/r05_linear_bwd_w_bf16x3_ab.log
 #endif
+typedef __attribute__((ext_vector_type(4))) __bf16 g_bf4;
 template <bool NT>     // NT: X does not fit the Infinity Cache and is read once per call: streamed non-temporal (as in the forward)
-__global__ __launch_bounds__(256) void linear_bwd_w_bf16x3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+__global__ __launch_bounds__(512) void linear_bwd_w_bf16x3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                                   float* __restrict__ part, float* __restrict__ dbpart, int n, int F,
                                                                   int n_chunk) {
     constexpr int S = MMREC_BWD_W_STAGES;
@@ -728,95 +732,96 @@ __global__ __launch_bounds__(256) void linear_bwd_w_bf16x3_kernel(const float* _
     __shared__ __attribute__((aligned(1024))) g_bf8 Asp[2][12 * 64];          // their split MFMA fragments [2 kstep + otile][part][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ft = wave & 3, ks = wave >> 2;
     const int f0 = blockIdx.x * BW_BF;
     const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
     const int rows = ne - nb;
     const i32x4 rx = raw_rsrc(X + (size_t)nb * F + f0, (unsigned)rows * (unsigned)F * 4u - (unsigned)f0 * 4u);
     const i32x4 rg = raw_rsrc(dY + (size_t)nb * 64, (unsigned)rows * 256u);
-    int vx[4], vg[2];
+    int vx[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vx[j] = (2 * (4 * wave + j) + (lane >> 5)) * F * 4 + (lane & 31) * 16;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) vg[j] = (4 * (2 * wave + j) + (lane >> 4)) * 256 + (lane & 15) * 16;
+    for (int j = 0; j < 2; ++j) vx[j] = (2 * (2 * wave + j) + (lane >> 5)) * F * 4 + (lane & 31) * 16;
+    const int vg = (4 * wave + (lane >> 4)) * 256 + (lane & 15) * 16;
     auto issue = [&](int t, int gb, int xb) {      // the dY tile FIRST: it is wanted one step before its X tile
+        lds_dma16<false>(rg, lds_addr(&Gq[gb][wave * 256]), vg, t * BW_BK * 256);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds_dma16<false>(rg, lds_addr(&Gq[gb][(2 * wave + j) * 256]), vg[j], t * BW_BK * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16<NT>(rx, lds_addr(&Xr[xb][(4 * wave + j) * 256]), vx[j], t * BW_BK * F * 4);
+        for (int j = 0; j < 2; ++j) lds_dma16<NT>(rx, lds_addr(&Xr[xb][(2 * wave + j) * 256]), vx[j], t * BW_BK * F * 4);
     };
     const int i = lane & 31, h = lane >> 5;
     const bool do_db = dbpart && blockIdx.x == 0 && tid < 64;
     f32x16 acc0 = {0}, acc1 = {0};
     float dbacc = 0.f;
-    // each dY element is split ONCE per workgroup: wave w owns fragment (kstep = w >> 1, otile = w & 1) of the tile
+    // each dY element is split ONCE per workgroup: wave w owns half (w & 1) of fragment (kstep = w >> 2, otile = (w >> 1) & 1)
     auto split_g = [&](int gb, int ab) {
         const float* gq = Gq[gb];
         if (do_db) {
 #pragma unroll
             for (int k = 0; k < BW_BK; ++k) dbacc += gq[k * 64 + tid];
         }
-        const float* gr = gq + (16 * (wave >> 1) + 8 * h) * 64 + 32 * (wave & 1) + i;
-        float gv[8];
+        const int frag = wave >> 1, half = wave & 1;
+        const float* gr = gq + (16 * (frag >> 1) + 8 * h + 4 * half) * 64 + 32 * (frag & 1) + i;
+        g_bf4 a1, a2, a3;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gv[e] = gr[e * 64];
-        g_bf8 a1, a2, a3;
-        split3(gv, a1, a2, a3);
-        g_bf8* dst = &Asp[ab][wave * 3 * 64 + lane];
+        for (int e = 0; e < 4; ++e) {
+            const float x = gr[e * 64];
+            const __bf16 b1 = (__bf16)x;
+            const float r1 = x - (float)b1;
+            const __bf16 b2 = (__bf16)r1;
+            a1[e] = b1;
+            a2[e] = b2;
+            a3[e] = (__bf16)(r1 - (float)b2);
+        }
+        g_bf4* dst = reinterpret_cast<g_bf4*>(&Asp[ab][frag * 3 * 64 + lane]) + half;
         dst[0] = a1;
-        dst[64] = a2;
-        dst[128] = a3;
+        dst[128] = a2;
+        dst[256] = a3;
     };
     auto compute = [&](int ab, int xb) {
-        const float* xs = Xr[xb];
+        const float* xr = Xr[xb] + (16 * ks + 8 * h) * BW_BF + 32 * ft + i;
+        g_bf8 b1, b2, b3;
+        {
+            float xv[8];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const float* xr = xs + (16 * st + 8 * h) * BW_BF + 32 * wave + i;
-            g_bf8 b1, b2, b3;
-            {
-                float xv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = xr[e * BW_BF];
-                split3(xv, b1, b2, b3);
-            }
-            {   // output tile 0 (o = i)
-                const g_bf8* ap = &Asp[ab][(2 * st) * 3 * 64 + lane];
-                const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc0, 0, 0, 0);
-            }
-            {   // output tile 1 (o = 32 + i)
-                const g_bf8* ap = &Asp[ab][(2 * st + 1) * 3 * 64 + lane];
-                const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128];
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc1, 0, 0, 0);
-            }
+            for (int e = 0; e < 8; ++e) xv[e] = xr[e * BW_BF];
+            split3(xv, b1, b2, b3);
+        }
+        {   // output tile 0 (o = i)
+            const g_bf8* ap = &Asp[ab][(2 * ks) * 3 * 64 + lane];
+            const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc0, 0, 0, 0);
+        }
+        {   // output tile 1 (o = 32 + i)
+            const g_bf8* ap = &Asp[ab][(2 * ks + 1) * 3 * 64 + lane];
+            const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc1, 0, 0, 0);
         }
     };
-    // vmcnt queue: [G(0) X(0)] [G(1) X(1)] ... (2 + 4 copies per tile and wave), S - 1 tiles ahead; tiles past the end are
-    // issued all the same (out of the descriptors' range: zero fill, no memory traffic) so that one count holds in every step:
-    // step t wants X(t) and G(t + 1), i.e. at most X(t + 1) and the S - 3 groups behind it still in flight.
+    // vmcnt queue: [G(0) X(0)] [G(1) X(1)] ... (1 + 2 copies per tile and wave), S - 1 tiles ahead, tiles past the end included
+    // (zero fill): step t wants X(t) and G(t + 1), i.e. at most X(t + 1) and the S - 3 groups behind it still in flight.
     const int T = (rows + BW_BK - 1) / BW_BK;
     if (T > 0) {
 #pragma unroll
         for (int u = 0; u < S - 1; ++u) issue(u, u, u);
-        MMREC_WAIT_VM(4 + 6 * (S - 2));
+        MMREC_WAIT_VM(2 + 3 * (S - 2));
         __builtin_amdgcn_s_barrier();
         split_g(0, 0);
     }
     int xb = 0, gb = 0;                                          // t % S, t % (S - 1)
     for (int t = 0; t < T; ++t) {
-        MMREC_WAIT_VM(4 + 6 * (S - 3));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment of tile t is in Asp
+        MMREC_WAIT_VM(2 + 3 * (S - 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's part of tile t's fragments is in Asp
         __builtin_amdgcn_s_barrier();
-        issue(t + S - 1, gb, xb == 0 ? S - 1 : xb - 1);          // into the buffers of tile t - 1 (X) and of tile t's dY (split in step t - 1)
+        issue(t + S - 1, gb, xb == 0 ? S - 1 : xb - 1);
         const int gn = gb == S - 2 ? 0 : gb + 1;
         if (t + 1 < T) split_g(gn, (t + 1) & 1);
         compute(t & 1, xb);
@@ -825,13 +830,29 @@ __global__ __launch_bounds__(256) void linear_bwd_w_bf16x3_kernel(const float* _
     }
     MMREC_WAIT_VM(0);      // (the zero-fill copies of the tiles past the end)
     if (do_db) dbpart[blockIdx.y * 64 + tid] = dbacc;
-    float* dst = part + (size_t)blockIdx.y * 64 * F;
-    const int f = f0 + wave * 32 + i;
+    // the two k-step halves: waves 4-7 hand theirs over through LDS (the X ring is free now: 64 x 128 floats)
+    float* red = &Xr[0][0];
+    static_assert(S * BW_BK * BW_BF >= 64 * BW_BF, "the X ring holds the 64 x 128 hand-over tile");
+    __builtin_amdgcn_s_barrier();
+    if (ks == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = d_row(r, lane);
-        dst[(size_t)o * F + f] = acc0[r];
-        dst[(size_t)(32 + o) * F + f] = acc1[r];
+        for (int r = 0; r < 16; ++r) {
+            const int o = d_row(r, lane);
+            red[o * BW_BF + ft * 32 + i] = acc0[r];
+            red[(32 + o) * BW_BF + ft * 32 + i] = acc1[r];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ks == 0) {
+        float* dst = part + (size_t)blockIdx.y * 64 * F;
+        const int f = f0 + ft * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = d_row(r, lane);
+            dst[(size_t)o * F + f] = acc0[r] + red[o * BW_BF + ft * 32 + i];
+            dst[(size_t)(32 + o) * F + f] = acc1[r] + red[(32 + o) * BW_BF + ft * 32 + i];
+        }
     }
 }
 
@@ -1142,13 +1163,20 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     float* slabs = reinterpret_cast<float*>(base + w.slabs);
     const int ncb = F / BW_BF;
     const bool big = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);      // X / dX larger than the Infinity Cache
+#ifdef MMREC_BWD_W_FP32      // probe: dW by the fp32-MFMA kernel inside the split entry (A/B against the bf16 x 3 kernel)
+    if (dW) {
+        const int rc = mmrec_linear_bwd_w_f32(dY, X, dW, db, n, F, out, workspace, stream);
+        if (rc) return rc;
+        dW = nullptr;
+    }
+#endif
     if (dW) {
         float* part = w.nsplit == 1 ? dW : slabs;
         float* dbpart = db ? dbp : (float*)nullptr;
         if (big && (MMREC_BWD_NT & 1))
-            hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(256), 0, s, dY, X, part, dbpart, n, F, w.chunk);
+            hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(512), 0, s, dY, X, part, dbpart, n, F, w.chunk);
         else
-            hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(256), 0, s, dY, X, part, dbpart, n, F, w.chunk);
+            hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(512), 0, s, dY, X, part, dbpart, n, F, w.chunk);
         if (w.nsplit > 1) {
             const size_t elems = (size_t)64 * F;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, (const float*)slabs,
