@@ -423,10 +423,9 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ X,
                                                            float* __restrict__ part,
                                                            float* __restrict__ dbpart, int n, int F,
-                                                           int n_chunk, int ldg, const int* __restrict__ redo) {
+                                                           int n_chunk, int ldg) {
     __shared__ __attribute__((aligned(16))) float Gs[BW_BK][64];
     __shared__ __attribute__((aligned(16))) float Xs[BW_BK][BW_BF];
-    if (redo && !(redo[blockIdx.x] | redo[gridDim.x])) return;      // (a flag-driven partial launch: unused since the dW path went to bf16 x 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * BW_BF;
     const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
@@ -497,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_w_dma_kernel(const float* _
                                                                   const float* __restrict__ X,
                                                                   float* __restrict__ part,
                                                                   float* __restrict__ dbpart, int n, int F,
-                                                                  int n_chunk, int ldg, const int* __restrict__ /*redo: unused*/) {
+                                                                  int n_chunk, int ldg) {
     __shared__ __attribute__((aligned(1024))) float G0[BW_BK * 64], G1[BW_BK * 64], G2[BW_BK * 64];
     __shared__ __attribute__((aligned(1024))) float X0[BW_BK * BW_BF], X1[BW_BK * BW_BF], X2[BW_BK * BW_BF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1227,11 +1226,9 @@ extern "C" int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW
                          !MMREC_GEMM_LEGACY_FWD;
         auto kern = dma ? linear_bwd_w_dma_kernel : linear_bwd_w_kernel;
         if (nsplit == 1) {
-            hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), 1), dim3(256), 0, s, g, X, dWz, dbpart, n, F, chunk,
-                               out, (const int*)nullptr);
+            hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), 1), dim3(256), 0, s, g, X, dWz, dbpart, n, F, chunk, out);
         } else {
-            hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), nsplit), dim3(256), 0, s, g, X, part, dbpart, n, F,
-                               chunk, out, (const int*)nullptr);
+            hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), nsplit), dim3(256), 0, s, g, X, part, dbpart, n, F, chunk, out);
             const size_t elems = (size_t)64 * F;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0,
                                s, part, nsplit, elems, (const float*)nullptr, dWz);
