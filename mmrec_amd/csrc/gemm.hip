@@ -820,8 +820,10 @@ __global__ __launch_bounds__(512) void linear_bwd_w_bf16x3_kernel(const float* _
         MMREC_WAIT_VM(2 + 3 * (S - 3));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's part of tile t's fragments is in Asp
         __builtin_amdgcn_s_barrier();
-        issue(t + S - 1, gb, xb == 0 ? S - 1 : xb - 1);
         const int gn = gb == S - 2 ? 0 : gb + 1;
+        // (the two waves of a SIMD running these phases in opposite order -- one's MFMAs under the other's copies and splits --
+        // measured 2 us slower at Baby size, 10 us at Sports size: the later copies cost more than the overlap gives)
+        issue(t + S - 1, gb, xb == 0 ? S - 1 : xb - 1);
         if (t + 1 < T) split_g(gn, (t + 1) & 1);
         compute(t & 1, xb);
         xb = xb == S - 1 ? 0 : xb + 1;
