@@ -997,7 +997,8 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dX = torch.empty_like(X)
         if LINEAR_F16X3 and n > 0 and F % 128 == 0:
-            # dW, db and dX in one call on the 16-bit matrix cores with split, power-of-two-scaled operands (ABI 11)
+            # dW, db and dX in one call on the 16-bit matrix cores with split operands (ABI 11: dW on three bf16 parts, dX on fp16
+            # halves scaled by exact powers of two)
             ws = _ws(lib.mmrec_linear_bwd_split_workspace_bytes(n, F, 64), X.device)
             _lib.check(lib.mmrec_linear_bwd_split_f32(_p(dY), _p(X), _p(W), _p(dW), _p(db), _p(dX), n, F, 64, _p(ws),
                                                       _stream()), "linear_bwd_split")
