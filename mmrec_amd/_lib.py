@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MMREC_HIP_LIB: load another build of the same library (kernel A/B measurements: tools/prof_topk_filter.py)
 LIB_PATH = os.environ.get("MMREC_HIP_LIB") or os.path.join(_PKG, "lib", "libmmrec_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _P = c_void_p  # every device/host pointer travels as void*
 
@@ -62,6 +62,8 @@ SIGNATURES = {
     "mmrec_topk_prepare_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),
     "mmrec_score_topk_prepared_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P,
                                                 c_int32, _P]),
+    "mmrec_score_topk_hinted_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, c_int32, _P,
+                                              _P, _P, _P, _P, c_int32, _P]),
     "mmrec_degree_count_i32": (c_int32, [_P, c_int64, _P, c_int32, _P]),
     "mmrec_edge_norm_f32": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P]),
     "mmrec_bipartite_expand": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P]),

@@ -71,6 +71,11 @@ class Trainer(AbstractTrainer):
         dm = config['hip_device_metrics']
         self.device_metrics = True if dm is None else bool(dm)
         self.eval_path, self.eval_paths = None, {}      # which path ranked the last evaluation / how often each one did
+        # new key `hip_eval_hint` (default on): the TEST pass after the VALID pass, and every later evaluation, hands the fused
+        # kernel last time's top-k lists so that it runs one matrix-core pass instead of two (models/_base.py); same results
+        self.eval_warm = (0, 0)                         # (warm, cold) batches of the last evaluation
+        if config['hip_eval_hint'] is not None and hasattr(model, 'eval_hint'):
+            model.eval_hint = bool(config['hip_eval_hint'])
         # new keys `hip_deterministic` (bitwise-repeatable training: position-ordered gradient scatters) and `hip_linear_split`
         # (False keeps the projection's forward on the fp32 matrix pipe).  Both switches are process-wide (hip_ops.DETERMINISTIC,
         # hip_ops.LINEAR_F16X3) and both are set on EVERY Trainer build -- to the config value, or with the key absent to the
@@ -269,9 +274,14 @@ class Trainer(AbstractTrainer):
     def evaluate(self, eval_data, is_test=False, idx=0):
         self.model.eval()
         k = max(self.config['topk'])
-        # WHICH path ranks this evaluation is recorded (self.eval_path, the result log line) and, with the new key
-        # `strict_fused_eval`, enforced: a benchmark that silently timed rocBLAS + torch.topk would be a different measurement
-        strict = bool(self.config['strict_fused_eval'])
+        # WHICH path ranks this evaluation is recorded (self.eval_path, the result log line) and enforced by the key
+        # `strict_fused_eval`: a benchmark that silently timed rocBLAS + torch.topk would be a different measurement.
+        # True: any reason for the dense path raises; False: never; 'auto' (the default): a shape of the tier -- evaluation
+        # tables 64 or 128 wide, max(topk) <= 128 -- that the kernel REFUSES raises instead of falling back with a warning;
+        # the reference's dense path stays reachable by `hip_fused_eval: False`.
+        strict_cfg = self.config['strict_fused_eval']
+        strict_auto = strict_cfg is None or str(strict_cfg).lower() == 'auto'
+        strict = (not strict_auto) and bool(strict_cfg)
         why_dense = None
         if not self.fused_eval:
             why_dense = 'hip_fused_eval: False'
@@ -292,7 +302,12 @@ class Trainer(AbstractTrainer):
                     continue
                 except Exception as ex:          # a shape the fused kernel does not serve: the reference's path
                     from mmrec_amd._lib import MMRecHipError
-                    if not isinstance(ex, MMRecHipError) or strict:
+                    try:                         # the width of the tables the evaluation ranks with (cached by the mixin)
+                        width = self.model._cached_eval_embeddings()[1].shape[1]
+                    except Exception:
+                        width = None
+                    in_tier = width in (64, 128) and k <= 128
+                    if not isinstance(ex, MMRecHipError) or strict or (strict_auto and in_tier):
                         raise
                     why_dense = 'the kernel refused the shape: %s' % ex
                     self.logger.warning('fused top-K evaluation unavailable for this model (%s); using the dense path' % ex)
@@ -301,6 +316,8 @@ class Trainer(AbstractTrainer):
         self.eval_path = 'fused HIP score + mask + top-K' if why_dense is None else \
             'dense (full_sort_predict + torch.topk, trainer.py:302-310): ' + why_dense
         self.eval_paths[self.eval_path] = self.eval_paths.get(self.eval_path, 0) + 1
+        if fused and hasattr(self.model, 'eval_hint_feedback'):
+            self.eval_warm = self.model.eval_hint_feedback()
         if self.device_metrics and topk_batches and topk_batches[0].is_cuda:
             return self.evaluator.evaluate_device(topk_batches, eval_data, is_test=is_test, idx=idx)
         return self.evaluator.evaluate(topk_batches, eval_data, is_test=is_test, idx=idx)

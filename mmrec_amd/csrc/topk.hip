@@ -659,7 +659,7 @@ extern "C" int mmrec_topk_prepare_f32(const float* C, int32_t nc, int32_t kd, vo
 static int score_topk_impl(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
                            int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col,
                            int32_t k, int64_t* out_idx, float* out_val, void* workspace,
-                           int32_t flags, mmrec_stream_t stream) {
+                           int32_t flags, mmrec_stream_t stream, const FilterHint& hint = FilterHint()) {
     if (nq < 0 || nc < 0 || kd <= 0 || (kd & 3)) return MMREC_ERR_UNSUPPORTED;
     if (flags & ~MMREC_TOPK_NO_FILTER) return MMREC_ERR_BAD_ARG;
     if (k <= 0 || k > MMREC_TOPK_MAX || k > nc) return MMREC_ERR_BAD_ARG;
@@ -671,7 +671,8 @@ static int score_topk_impl(const float* Q, const float* C, const void* prepared,
     char* ws = static_cast<char*>(workspace);
     hipStream_t s = mmrec_stream(stream);
     if (p.materialise && !(flags & MMREC_TOPK_NO_FILTER) && topk64_filter_applicable(nq, nc, kd, k))
-        return topk64_filter_launch(Q, C, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
+        return topk64_filter_launch(Q, C, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s, hint);
+    if (hint.ids) return MMREC_ERR_UNSUPPORTED;      // a warm call is a call of the fp16 filter
     if (!p.materialise && k > MMREC_TOPK_MAX_OTHER) return MMREC_ERR_UNSUPPORTED;   // 65..128: not on the fused fp32 path (kd % 32 != 0)
     if (p.materialise) {
         float* Ct = nullptr;
@@ -757,4 +758,16 @@ extern "C" int mmrec_score_topk_prepared_f32(const float* Q, const float* C, con
                                              int32_t flags, mmrec_stream_t stream) {
     if (!prepared) return MMREC_ERR_BAD_ARG;
     return score_topk_impl(Q, C, prepared, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, flags, stream);
+}
+
+extern "C" int mmrec_score_topk_hinted_f32(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
+                                           int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
+                                           const int32_t* hint, int32_t hint_k, const int64_t* hint_rows,
+                                           int64_t* out_idx, float* out_val, void* workspace, int32_t* queue_counts,
+                                           int32_t flags, mmrec_stream_t stream) {
+    if (!hint || hint_k < k || hint_k > MMREC_TOPK_MAX || flags != 0) return MMREC_ERR_BAD_ARG;
+    if (nq > 0 && nc > 0 && !topk64_filter_applicable(nq, nc, kd, k)) return MMREC_ERR_UNSUPPORTED;
+    FilterHint h;
+    h.ids = hint; h.hk = hint_k; h.rows = hint_rows; h.queue_counts = queue_counts;
+    return score_topk_impl(Q, C, prepared, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, 0, stream, h);
 }

@@ -562,6 +562,39 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
 }
 
 
+// Shared tail of the two bound kernels (one wave per query): B = a lower bound, in approximate-score units, of the
+// query's k-th best unmasked candidate's APPROXIMATE score  ->  thr[q] = B - 2 eps_q, flag[q] = 0; or, where clipped
+// candidate rows make B unusable (B < eps), thr = +inf and flag = 1 (the exact slow queue).
+// eps in the scaled (by the query's own and the candidates' power of two), centred units of the approximate
+// scores: fp16 rounding of both operands (2u + u^2 and
+// the accumulation, 1.0e-3 of |q| max|c'|) plus the fp32 rounding of the EXACT scores the final kernel ranks by
+// (kd * 2^-24 of |q| max|c|, the uncentred norm: |c| <= |c'| + |mean|)
+__device__ __forceinline__ void filter_eps_store(float B, int q, int lane, int nc, int kd, const float* __restrict__ qnorm,
+                                                 const unsigned* __restrict__ cmax_key, const float* __restrict__ stats,
+                                                 float* __restrict__ thr, int* __restrict__ flag) {
+    float mu = 0.f;
+    for (int c = lane; c < kd; c += 64) {
+        const float mc = stats[c] / (float)nc;
+        mu = fmaf(mc, mc, mu);
+    }
+    mu = wave_sum(mu);
+    if (lane == 0) {
+        const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
+        const float cmax = key2f(*cmax_key);
+        const float kb = (float)kd * (1.f / 64.f);
+        // + 2^-25 sqrt(kd) (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
+        // (sum |x_i| <= sqrt(kd) |x|; 2.4e-7 = 2^-22 for kd = 64)
+        const bool clipped = reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
+        const float cmax0 = clipped ? key2f(reinterpret_cast<const unsigned*>(stats)[ST_NMAX0]) : cmax;   // before clipping
+        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax0 + sc * sqrtf(mu))) +
+                          2.4e-7f * sqrtf(kb) * (qnorm[q] + cmax);
+        // clipped candidate rows are lower bounds of real scores only where the bound is >= eps
+        const bool ok = !clipped || B >= eps;
+        thr[q] = ok ? B - 2.f * eps : INFINITY;
+        flag[q] = ok ? 0 : 1;
+    }
+}
+
 // thr[q] = (k + m)-th largest group maximum - 2 eps_q; queries the filter cannot serve are flagged and
 // get thr = +inf (nothing passes).  One wave per query.
 __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __restrict__ gkeys, int n_groups, int nq,
@@ -613,31 +646,122 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
         for (int j = 0; j < 8; ++j) c += __popcll(__ballot(key[j] >= trial));
         if (c >= rank) cur = trial;
     }
-    // eps in the scaled (by the query's own and the candidates' power of two), centred units of the approximate
-    // scores: fp16 rounding of both operands (2u + u^2 and
-    // the accumulation, 1.0e-3 of |q| max|c'|) plus the fp32 rounding of the EXACT scores the final kernel ranks by
-    // (kd * 2^-24 of |q| max|c|, the uncentred norm: |c| <= |c'| + |mean|)
-    float mu = 0.f;
-    for (int c = lane; c < kd; c += 64) {
-        const float mc = stats[c] / (float)nc;
-        mu = fmaf(mc, mc, mu);
+    // eps in the scaled, centred units of the approximate scores: see filter_eps_store
+    filter_eps_store(key2f(cur), q, lane, nc, kd, qnorm, cmax_key, stats, thr, flag);
+}
+
+// WARM calls (mmrec_score_topk_hinted_f32): the threshold WITHOUT pass 1.  The caller hands over, per query, a list of
+// `hk` candidate ids it believes rank high -- the previous evaluation's top-k of that user, or the VALID pass's list when the
+// TEST pass follows on the same frozen tables (trainer.py:262,271: same train-positive mask).  ANY k distinct, unmasked,
+// in-range candidates bound the k-th best score from below: with a_j their approximate scores (the SAME fp16 operands pass 2
+// multiplies -- Qs, Cs -- products exact in fp32, fp32 accumulation: |a_j - s_j| <= eps_q by the bound stated at the head of
+// this file, which never depended on the accumulation order), B = min_j a_j gives k unmasked candidates with exact score >=
+// B - eps, so every true top-k candidate has exact score >= B - eps and approximate score >= B - 2 eps =: thr -- the cold
+// path's argument with the (k + m)-th group maximum replaced by B (no "+ m": the listed ids are checked against the mask).
+// Clipped rows (large candidate sets): a listed clipped row's stored score approximates f s, f < 1; as in the cold path it is
+// a lower bound of s where B >= eps (filter_eps_store checks).  A STALE list only loosens thr (more survivors for the exact
+// refinement, the overflow / slow queues beyond that); a list with fewer than k usable ids sends the query to the exact slow
+// queue: results never depend on the hint.  One wave per query; W = kd / 8 lanes per listed row (16-B fp16 chunks).
+template <int KB>
+__global__ __launch_bounds__(256) void filter_hint_bound_kernel(const uint4* __restrict__ Qs, const uint4* __restrict__ Cs,
+                                                                const int32_t* __restrict__ hint, int hk,
+                                                                const int64_t* __restrict__ hint_rows, int nq, int nc, int k,
+                                                                const int32_t* __restrict__ mask_rowptr,
+                                                                const int32_t* __restrict__ mask_col,
+                                                                const float* __restrict__ qnorm,
+                                                                const unsigned* __restrict__ cmax_key,
+                                                                const float* __restrict__ stats, float* __restrict__ thr,
+                                                                int* __restrict__ flag) {
+    constexpr int W = 8 * KB, RPS = 64 / W;     // lanes per row, rows per wave step
+    __shared__ int s_id[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;                        // waves are independent below (wave-level fences only)
+    const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
+    if (nc - m < k) {
+        if (lane == 0) { thr[q] = INFINITY; flag[q] = 1; }
+        return;
     }
-    mu = wave_sum(mu);
-    if (lane == 0) {
-        const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
-        const float cmax = key2f(*cmax_key);
-        const float kb = (float)kd * (1.f / 64.f);
-        // + 2^-25 sqrt(kd) (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
-        // (sum |x_i| <= sqrt(kd) |x|; 2.4e-7 = 2^-22 for kd = 64)
-        const bool clipped = reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
-        const float cmax0 = clipped ? key2f(reinterpret_cast<const unsigned*>(stats)[ST_NMAX0]) : cmax;   // before clipping
-        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax0 + sc * sqrtf(mu))) +
-                          2.4e-7f * sqrtf(kb) * (qnorm[q] + cmax);
-        // clipped candidate rows are lower bounds of real scores only where the bound is >= eps
-        const bool ok = !clipped || key2f(cur) >= eps;
-        thr[q] = ok ? key2f(cur) - 2.f * eps : INFINITY;
-        flag[q] = ok ? 0 : 1;
+    if (qnorm[q] == 0.f) {                      // all scores tie at 0: the final kernel writes the k lowest unmasked ids
+        if (lane == 0) { thr[q] = INFINITY; flag[q] = 2; }
+        return;
     }
+    const int32_t* hrow = hint + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk;
+    int id[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u;
+        id[u] = e < hk ? hrow[e] : -1;
+        s_id[wave][e] = id[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        ok[u] = id[u] >= 0 && id[u] < nc;
+        if (ok[u] && m > 0) {                   // masked (train-positive) ids bound nothing
+            const int32_t* ml = mask_col + m_lo;
+            int lo = 0, hi = m;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ml[mid] < id[u]) lo = mid + 1; else hi = mid;
+            }
+            ok[u] = !(lo < m && ml[lo] == id[u]);
+        }
+    }
+    for (int j = 0; j < hk; ++j) {              // an id counts once: its first occurrence (broadcast LDS reads)
+        const int v = s_id[wave][j];
+        if (j < lane && v == id[0]) ok[0] = false;
+        if (j < lane + 64 && v == id[1]) ok[1] = false;
+    }
+    const int n_ok = __popcll(__ballot(ok[0])) + __popcll(__ballot(ok[1]));
+    if (n_ok < k) {                             // not enough to bound the k-th score: the exact slow queue
+        if (lane == 0) { thr[q] = INFINITY; flag[q] = 1; }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < hk && !ok[u]) s_id[wave][lane + 64 * u] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // approximate scores of the listed rows from the operands pass 2 multiplies
+    const int ch = lane % W, sub = lane / W;
+    const half8 qh = __builtin_bit_cast(half8, Qs[(size_t)q * W + ch]);
+    float qf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[j] = (float)qh[j];
+    float bmin = INFINITY;
+    constexpr int NB = 4;                       // row steps in flight
+    for (int e0 = 0; e0 < hk; e0 += RPS * NB) {
+        int rid[NB];
+        uint4 cv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int e = e0 + b * RPS + sub;
+            rid[b] = e < hk ? s_id[wave][e] : -1;
+            const int r = rid[b] >= 0 ? rid[b] : 0;
+            cv[b] = Cs[(((size_t)(r >> 6) * KB + (ch >> 3)) * 64 + (r & 63)) * 8 + (ch & 7)];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const half8 chv = __builtin_bit_cast(half8, cv[b]);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf(qf[j], (float)chv[j], a);
+#pragma unroll
+            for (int o = W / 2; o >= 1; o >>= 1) a += __shfl_xor(a, o, W);
+            if (rid[b] >= 0) bmin = fminf(bmin, a);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bmin = fminf(bmin, __shfl_xor(bmin, o, 64));
+    filter_eps_store(bmin, q, lane, nc, 64 * KB, qnorm, cmax_key, stats, thr, flag);
+}
+
+// queue_counts[0] += queries the exact slow queue served, [1] += queries that went through the overflow queue (either is a
+// sign of a loose threshold: a warm caller falls back to the cold path when they grow)
+__global__ void filter_counts_add_kernel(const int* __restrict__ n_flagged, int* __restrict__ queue_counts) {
+    queue_counts[0] += n_flagged[0];
+    queue_counts[1] += n_flagged[1];
 }
 
 // exact fp32 score = fixed tree over the 16 float4 chunk products (identical in the final and slow kernels)
@@ -1193,7 +1317,7 @@ namespace {
 template <int KB>
 int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32_t* mask_rowptr,
                      const int32_t* mask_col, int k, int64_t* out_idx, float* out_val, void* workspace,
-                     const void* prepared, hipStream_t s) {
+                     const void* prepared, const FilterHint& hint, hipStream_t s) {
     constexpr int kd = 64 * KB;
     const FilterPlan p = filter_plan(nq, nc);
     char* ws = static_cast<char*>(workspace);
@@ -1226,9 +1350,14 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
                        stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
     PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist};
     const dim3 grid(p.qblocks, p.R);
-    hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
-                       mask_rowptr, qnorm, cmax, stats, kd, thr, flag);
+    if (hint.ids) {      // warm: the threshold from the caller's lists, no pass 1
+        hipLaunchKernelGGL(filter_hint_bound_kernel<KB>, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Qs, Cs, hint.ids, hint.hk, hint.rows,
+                           nq, nc, k, mask_rowptr, mask_col, qnorm, cmax, stats, thr, flag);
+    } else {
+        hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
+                           mask_rowptr, qnorm, cmax, stats, kd, thr, flag);
+    }
     if (p.sparse)
         hipLaunchKernelGGL((filter_pass_kernel<true, true, KB>), grid, dim3(256), 0, s, a);
     else
@@ -1252,13 +1381,15 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     if (want > 1)
         hipLaunchKernelGGL(filter_slow_merge_kernel, dim3(64), dim3(256), 0, s, flist, n_flagged, want, parts, k, out_idx,
                            out_val);
+    if (hint.queue_counts)
+        hipLaunchKernelGGL(filter_counts_add_kernel, dim3(1), dim3(1), 0, s, n_flagged, hint.queue_counts);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 }  // namespace
 
 int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, int kd, const int32_t* mask_rowptr,
                          const int32_t* mask_col, int k, int64_t* out_idx, float* out_val, void* workspace,
-                         const void* prepared, hipStream_t s) {
-    return kd == 64 ? filter_launch_kb<1>(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s)
-                    : filter_launch_kb<2>(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, s);
+                         const void* prepared, hipStream_t s, const FilterHint& hint) {
+    return kd == 64 ? filter_launch_kb<1>(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, hint, s)
+                    : filter_launch_kb<2>(Q, C, nq, nc, mask_rowptr, mask_col, k, out_idx, out_val, workspace, prepared, hint, s);
 }

@@ -1100,11 +1100,21 @@ class TopkCandidates:
             _lib.check(lib.mmrec_topk_prepare_f32(_p(self.C), nc, kd, _p(self.prepared), _stream()), "topk_prepare")
 
 
-def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True):
+def topk_hint_served(nc, kd, k):
+    """does the warm entry point (mmrec_score_topk_hinted_f32) serve this candidate table / k?  (the fp16 filter's shapes)"""
+    return k <= TOPK_MAX and _lib.load().mmrec_topk_prepared_bytes(int(nc), int(kd)) > 0
+
+
+def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True, hint=None, hint_rows=None,
+               queue_counts=None):
     """top-k over candidates c of <Q[q], C[c]> per query with masked candidates at -1e10; never
     materialises the score matrix.  Returns int64 [nq, k] sorted by score desc (ties: lower id).
     C: a tensor, or a TopkCandidates (the candidate-side preparation of the fp16 filter done once for many calls).
-    use_filter=False keeps the materialised fp32 path where the fp16 filter would serve the call (A/B measurements)."""
+    use_filter=False keeps the materialised fp32 path where the fp16 filter would serve the call (A/B measurements).
+    hint (int32 [rows, hk >= k], with hint_rows int64 [nq] or one row per query): a WARM call -- per query a list of ids
+    expected to rank high (a previous call's output for the same user); the filter takes its threshold from them and runs ONE
+    matrix-core pass instead of two.  The result does not depend on the hint (bit-identical to the cold call); shapes the
+    filter does not serve ignore it.  queue_counts (int32 [2], device): += queries the slow / overflow queues served."""
     lib = _lib.load()
     Q = _chk(Q.contiguous(), torch.float32, "Q", 2)
     prepared = None
@@ -1120,12 +1130,30 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
         if mask_col is None or mask_col.numel() == 0:
             mask_col = torch.zeros(1, dtype=torch.int32, device=Q.device)
         _chk(mask_col, torch.int32, "mask_col", 1)
+    if hint is not None and not (use_filter and nc >= k and topk_hint_served(nc, kd, k)):
+        hint = None
+    if hint is not None:
+        _chk(hint, torch.int32, "hint", 2)
+        if hint.shape[1] < k or hint.shape[1] > TOPK_MAX:
+            raise _lib.MMRecHipError("hint rows hold k <= hk <= %d ids, got %d for k = %d" % (TOPK_MAX, hint.shape[1], k))
+        if hint_rows is not None:
+            _chk(hint_rows, torch.int64, "hint_rows", 1)
+            if hint_rows.numel() != nq:
+                raise _lib.MMRecHipError("hint_rows: one row index per query")
+        elif hint.shape[0] != nq:
+            raise _lib.MMRecHipError("hint: one row per query (or pass hint_rows)")
+        if queue_counts is not None:
+            _chk(queue_counts, torch.int32, "queue_counts", 1)
     if nq > 2 * TOPK_QUERY_BLOCK and use_filter and (prepared is not None or lib.mmrec_topk_prepared_bytes(nc, kd) > 0):
-        return _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values)
+        return _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values, hint, hint_rows, queue_counts)
     idx = torch.empty(nq, k, dtype=torch.int64, device=Q.device)
     val = torch.empty(nq, k, dtype=torch.float32, device=Q.device) if return_values else None
     ws = _ws(lib.mmrec_topk_workspace_bytes(nq, nc, kd, k), Q.device)
-    if prepared is not None:
+    if hint is not None:
+        _lib.check(lib.mmrec_score_topk_hinted_f32(_p(Q), _p(C), _p(prepared), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
+                                                   _p(hint), hint.shape[1], _p(hint_rows), _p(idx), _p(val), _p(ws),
+                                                   _p(queue_counts), 0, _stream()), "score_topk_hinted")
+    elif prepared is not None:
         _lib.check(lib.mmrec_score_topk_prepared_f32(_p(Q), _p(C), _p(prepared), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
                                                      _p(idx), _p(val), _p(ws), 0, _stream()), "score_topk_prepared")
     else:
@@ -1138,7 +1166,7 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
 TOPK_QUERY_BLOCK = 65536     # the Trainer's `hip_eval_batch_size`: 256 query blocks x 16 candidate ranges = 8 exact rounds of workgroups
 
 
-def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values):
+def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values, hint=None, hint_rows=None, queue_counts=None):
     """Very many queries in ONE call (a script ranking all 1M users at once): the fp16 filter's workspace is per query
     (~16 KB of word list at 500K candidates: 16 GB for 1M queries), so the call is walked in blocks of TOPK_QUERY_BLOCK queries
     against ONE preparation of the candidates -- what the Trainer's evaluation batches amount to.  One small device -> host
@@ -1159,7 +1187,10 @@ def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values)
         if mask_rowptr is not None:
             rp = (mask_rowptr[a:b + 1] - offs[j]).contiguous()
             col = mask_col[offs[j]:max(offs[j + 1], offs[j] + 1)].contiguous()
-        out = score_topk(Q[a:b], cands, k, rp, col, return_values=return_values)
+        h = hr = None
+        if hint is not None:
+            h, hr = (hint, hint_rows[a:b]) if hint_rows is not None else (hint[a:b], None)
+        out = score_topk(Q[a:b], cands, k, rp, col, return_values=return_values, hint=h, hint_rows=hr, queue_counts=queue_counts)
         if return_values:
             idx[a:b], val[a:b] = out
         else:

@@ -23,10 +23,21 @@ class FusedEvalMixin:
     SURVEY.md App. C.4).  The cache is dropped whenever the module goes back to train mode."""
 
     _eval_cache = None
+    _tables_version = 0
+    # False for a plugin whose evaluation forward DRAWS random numbers (LGMRec's Gumbel noise): the reference recomputes the
+    # forward in every evaluation pass, and so must such a plugin, or the generator's stream -- and the next epoch -- differs
+    eval_tables_deterministic = True
 
     def train(self, mode=True):
-        self._eval_cache = self._eval_cands = None
+        # dropped when training starts or ends; eval() -> eval() (the VALID and the TEST pass of one evaluation,
+        # trainer.py:262,271: nothing was trained in between) keeps the propagated tables and the prepared candidates
+        if mode or self.training or not self.eval_tables_deterministic:
+            self._eval_cache = self._eval_cands = None
         return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._eval_cache = self._eval_cands = None      # new weights: nothing cached in eval mode describes them
+        return super().load_state_dict(*args, **kwargs)
 
     def eval_embeddings(self):
         """-> (user_all [n_users, d], item_all [n_items, d]) used by full_sort_*; override."""
@@ -41,6 +52,7 @@ class FusedEvalMixin:
                 return cache
             self._eval_cache = cache
             self._eval_cands = None
+            self._tables_version += 1           # (warm evaluation: lists written under THESE tables are exact for them)
         return self._eval_cache
 
     _eval_cands = None
@@ -83,10 +95,73 @@ class FusedEvalMixin:
             rowptr, cols = mask_to_csr_device(mask, users.shape[0], i.shape[0])
             if cache is not None:
                 cache[key] = (rowptr, cols)
-        if rl is None:
-            return hip_ops.score_topk(u[users].contiguous(), cands, k, rowptr, cols)
+        q = u[users if rl is None else rl.perm_u[users]].contiguous()
+        out = self._ranked_with_hint(interaction, users, q, cands, k, rowptr, cols)
         # ranked in the relabelled space (ties between EXACTLY equal scores go to the lower relabelled id), reported in the dataset's ids
-        return rl.inv_i[hip_ops.score_topk(u[rl.perm_u[users]].contiguous(), cands, k, rowptr, cols)]
+        return out if rl is None else rl.inv_i[out]
+
+    # ---- WARM evaluation (new config key `hip_eval_hint`, default on): the fp16 filter needs a per-user threshold before its
+    # products; a cold call gets it from a first pass over ALL products, a warm call from the k ids ranked for that user LAST
+    # time -- the VALID pass's list when the TEST pass follows on the same frozen tables (trainer.py:262,271), the previous
+    # epoch's list otherwise -- rescored under the current tables (mmrec_score_topk_hinted_f32): one matrix-core pass instead
+    # of two, the same exact top-k.  The lists live on the device ([n_users, k] int32, candidate ids as the kernel reports
+    # them); which users have one -- and under which evaluation tables it was written -- is tracked on the host, so a batch is
+    # only ranked warm when every user of it has a list.
+    eval_hint = True
+    _hint = None
+    HINT_STALE_FRAC = 0.02      # more than this share of an evaluation's queries in the overflow / slow queues: next one is cold
+
+    def _ranked_with_hint(self, interaction, users, q, cands, k, rowptr, cols):
+        import numpy as np
+        nc = cands.C.shape[0] if isinstance(cands, hip_ops.TopkCandidates) else cands.shape[0]
+        if (not self.eval_hint or self.training or nc < k
+                or not hip_ops.topk_hint_served(nc, q.shape[1], k)):
+            return hip_ops.score_topk(q, cands, k, rowptr, cols)
+        st = self._hint
+        if st is None or st['k'] != k or st['nc'] != nc or st['table'].device != q.device:
+            st = self._hint = dict(k=k, nc=nc, table=torch.full((self.n_users, k), -1, dtype=torch.int32, device=q.device),
+                                   ver=np.zeros(self.n_users, dtype=np.int64), cold_from=0, warm=0, cold=0, queries=0,
+                                   counts=torch.zeros(2, dtype=torch.int32, device=q.device))
+        cache = getattr(interaction, 'cache', None)
+        key = ('users_host', getattr(interaction, 'cache_key', None))
+        if cache is not None and key in cache:
+            users_np = cache[key]
+        else:
+            users_np = users.detach().cpu().numpy()
+            if cache is not None:
+                cache[key] = users_np
+        # a list exists for every user of the batch; after a pass whose lists had gone stale (eval_hint_feedback) only lists
+        # written under the CURRENT tables count (the TEST pass after a cold VALID pass), until a cold pass has refreshed them
+        oldest = int(st['ver'][users_np].min()) if users_np.shape[0] else 0
+        warm = oldest > 0 and (oldest >= st['cold_from'] or oldest == self._tables_version)
+        if warm:
+            out = hip_ops.score_topk(q, cands, k, rowptr, cols, hint=st['table'], hint_rows=users, queue_counts=st['counts'])
+            if oldest != self._tables_version:           # lists of EARLIER tables: the ones that can be stale
+                st['queries'] += users_np.shape[0]
+        else:
+            out = hip_ops.score_topk(q, cands, k, rowptr, cols)
+        st['warm' if warm else 'cold'] += 1
+        st['table'][users] = out.to(torch.int32)
+        st['ver'][users_np] = self._tables_version
+        return out
+
+    def eval_hint_feedback(self):
+        """Called by the Trainer once an evaluation's lists are on the host anyway: how many warm queries needed the overflow /
+        slow queues (one 8-byte read).  Above HINT_STALE_FRAC the rankings have moved too far for last time's lists -- from
+        then on only lists written under the tables being evaluated are used (the TEST pass after the VALID pass), i.e. the
+        next evaluation's first pass runs cold and refreshes them.  -> (warm batches, cold batches) of this pass."""
+        st = self._hint
+        if st is None:
+            return 0, 0
+        if st['queries']:                                # warm queries ranked from lists of earlier tables
+            slow, over = st['counts'].tolist()
+            stale = (slow + over) > self.HINT_STALE_FRAC * st['queries']
+            st['cold_from'] = self._tables_version + 1 if stale else 0
+            st['last_queues'] = (slow, over, st['queries'])
+        st['counts'].zero_()
+        done = (st['warm'], st['cold'])
+        st['warm'] = st['cold'] = st['queries'] = 0
+        return done
 
 
 class RelabelledIdsMixin:

@@ -37,6 +37,7 @@ class HGNNLayer(nn.Module):
 
 class LGMRec(FusedEvalMixin, GeneralRecommender):
     graph_capturable = False      # Gumbel noise and dropout are drawn inside the step
+    eval_tables_deterministic = False   # ... and inside the evaluation forward: recomputed per evaluation pass like the reference
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)

@@ -246,7 +246,16 @@ class TopkCandidates:
         self.C, self.prepared = C.contiguous(), None
 
 
-def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True):
+def topk_hint_served(nc, kd, k):
+    return k <= 128 and kd in (64, 128) and 4096 <= nc <= 1000000
+
+
+def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True, hint=None, hint_rows=None,
+               queue_counts=None):
+    """(a warm call's hint never changes the result: the stand-in checks its shape and ignores it)"""
+    if hint is not None:
+        assert hint.dtype == torch.int32 and hint.dim() == 2 and k <= hint.shape[1] <= 128
+        assert (hint_rows is None and hint.shape[0] == Q.shape[0]) or (hint_rows.dtype == torch.int64 and hint_rows.numel() == Q.shape[0])
     if isinstance(C, TopkCandidates):
         C = C.C
     _mat(Q, "Q"), _mat(C, "C", width=Q.shape[1])
@@ -299,7 +308,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "TopkCandidates", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "topk_hint_served", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

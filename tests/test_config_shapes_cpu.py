@@ -10,7 +10,7 @@ from tests.test_config_shapes_gpu import (  # noqa: F401  (collected here withou
     test_knn_graph_at_sports_item_count)
 from tests.test_config_shapes_gpu import (  # noqa: F401  (golden at full Amazon-Baby shape: small enough for the CPU stand-ins)
     test_lattice_step_vs_reference_golden_at_baby_shape, test_mmgcn_step_vs_reference_golden_at_baby_shape,
-    test_eval_rows_of_128_at_baby_shape)
+    test_eval_rows_of_128_at_baby_shape, test_trainer_warm_evaluation_equals_cold)
 
 
 @pytest.fixture(autouse=True)

@@ -365,6 +365,103 @@ def test_score_topk_c5_block_vs_oracle():
     topk_rows_match(idx, scores, local_mask(mask[0], mask[1], rows), k, rows)
 
 
+def _stale_lists(U, I, k, rel, seed):
+    """top-k lists of tables that have MOVED since (every element perturbed by `rel` of its row's mean magnitude): what the
+    previous epoch's evaluation left behind.  Unmasked on purpose: some of the listed ids are train positives now."""
+    from mmrec_amd import hip_ops
+    gen = torch.Generator(device=U.device).manual_seed(seed)
+    Un = U + rel * U.abs().mean(1, keepdim=True) * torch.randn(U.shape, device=U.device, generator=gen)
+    In = I + rel * I.abs().mean(1, keepdim=True) * torch.randn(I.shape, device=I.device, generator=gen)
+    return hip_ops.score_topk(Un, In, k).to(torch.int32)
+
+
+@pytest.mark.parametrize("shape", ["baby", "sports"])
+def test_score_topk_warm_call_at_eval_shapes(shape):
+    """mmrec_score_topk_hinted_f32 (ABI 12; round-5 review, next 1) at 19,445 x 7,050 and 35,598 x 18,357, k = 50, train
+    positives masked: the threshold comes from a list per user instead of a first pass over all products.  With the cold
+    call's own lists (the TEST pass after the VALID pass), with the lists of tables that moved by 5 % and 50 % per element
+    (a later epoch), read through `hint_rows` from a table keyed by user id: ids AND values equal the cold call's bit for bit
+    (which tests/test_config_shapes_gpu.py::test_score_topk_at_eval_shapes checks against the oracle), and fresh lists
+    leave the overflow queue empty."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    nu, ni, eu, ei, U, I = _eval_case(shape, dev)
+    rp, col = hip_ops.mask_to_csr(np.stack([eu, ei]), nu, dev)
+    cands = hip_ops.TopkCandidates(I)
+    idx, val = hip_ops.score_topk(U, cands, 50, rp, col, return_values=True)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    widx, wval = hip_ops.score_topk(U, cands, 50, rp, col, return_values=True, hint=idx.to(torch.int32), queue_counts=counts)
+    assert torch.equal(widx, idx) and torch.equal(wval, val)
+    slow_fresh, over_fresh = counts.tolist()
+    assert over_fresh == 0 and slow_fresh <= 8, (slow_fresh, over_fresh)      # (slow: users with fewer than k unmasked items, if any)
+    perm = torch.randperm(nu + 11, device=dev)[:nu]
+    for rel in (0.05, 0.5):
+        table = torch.full((nu + 11, 50), -1, dtype=torch.int32, device=dev)
+        table[perm] = _stale_lists(U, I, 50, rel, 11)
+        counts.zero_()
+        widx, wval = hip_ops.score_topk(U, cands, 50, rp, col, return_values=True, hint=table, hint_rows=perm, queue_counts=counts)
+        assert torch.equal(widx, idx) and torch.equal(wval, val), rel
+        print("%s warm call, lists of tables moved by %.0f %%: slow queue %d, overflow queue %d of %d queries" %
+              ((shape, 100 * rel) + tuple(counts.tolist()) + (nu,)))
+
+
+def test_score_topk_warm_call_c5_block():
+    """The same at config 5's shape: a 20,000-user block against 500,000 items (word lists, subsampled pass 1 and clipped
+    outlying rows on the cold side), 16 masked items per user, k = 50 -- own lists, lists of moved tables, and lists with
+    unusable entries (the exact slow queue serves those users): bit-identical to the cold call."""
+    from mmrec_amd import hip_ops
+    dev = _dev()
+    nq, nc, k = 20_000, 500_000, 50
+    gen = torch.Generator().manual_seed(9)
+    common = torch.randn(64, generator=gen) * 0.05
+    Q = (torch.randn(nq, 64, generator=gen) * 0.03 + common).to(dev)
+    C = torch.randn(nc, 64, generator=gen) * 0.03 + common
+    C[torch.randint(0, nc, (5,), generator=gen)] *= 20.0            # outlying rows: clipped in the fp16 copy, always rescored
+    C = C.to(dev)
+    mrow = np.repeat(np.arange(nq), 16)
+    mcol = np.random.default_rng(2).integers(0, nc, nq * 16)
+    key = np.unique(mrow.astype(np.int64) * nc + mcol)
+    rp, col = hip_ops.mask_to_csr(np.stack([key // nc, key % nc]), nq, dev)
+    cands = hip_ops.TopkCandidates(C)
+    idx, val = hip_ops.score_topk(Q, cands, k, rp, col, return_values=True)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    for name, hint in (("own", idx.to(torch.int32)), ("moved 5 %", _stale_lists(Q, C, k, 0.05, 5)),
+                       ("moved 30 %", _stale_lists(Q, C, k, 0.3, 6))):
+        counts.zero_()
+        widx, wval = hip_ops.score_topk(Q, cands, k, rp, col, return_values=True, hint=hint, queue_counts=counts)
+        assert torch.equal(widx, idx) and torch.equal(wval, val), name
+        print("c5 block warm call (%s lists): slow queue %d, overflow queue %d of %d queries" % ((name,) + tuple(counts.tolist()) + (nq,)))
+    junk = idx.to(torch.int32).clone()
+    junk[::97, 3] = -1                                              # k - 1 usable ids: those users go to the exact slow queue
+    junk[5::101, 7] = junk[5::101, 8]
+    counts.zero_()
+    widx, wval = hip_ops.score_topk(Q, cands, k, rp, col, return_values=True, hint=junk, queue_counts=counts)
+    assert torch.equal(widx, idx) and torch.equal(wval, val)
+    assert counts[0].item() >= len(range(0, nq, 97))
+
+
+def test_trainer_warm_evaluation_equals_cold(tmp_path):
+    """`hip_eval_hint` through the plugin API at Amazon-Baby shape (LightGCN): the first evaluation is cold, the second pass
+    over the same users and the evaluation after a training epoch are warm (Trainer.eval_warm), and every metric equals a
+    Trainer's with `hip_eval_hint: False` on the same weights."""
+    from mmrec_amd.common.trainer import Trainer
+    config, train_data, valid_data, model = build_shape(tmp_path, "LightGCN", "baby", {"n_layers": 3, "reg_weight": 1e-4})
+    trainer = Trainer(config, model)
+    first = trainer.evaluate(valid_data)
+    assert trainer.eval_warm[0] == 0 and trainer.eval_warm[1] >= 1
+    again = trainer.evaluate(valid_data)
+    assert again == first and trainer.eval_warm[1] == 0 and trainer.eval_warm[0] >= 1
+    trainer._train_epoch(train_data, 0)
+    warm = trainer.evaluate(valid_data)
+    assert trainer.eval_warm[1] == 0 and trainer.eval_warm[0] >= 1 and trainer.eval_path.startswith("fused")
+    assert warm != first                                            # (the epoch changed the ranking)
+    config["hip_eval_hint"] = False
+    cold_trainer = Trainer(config, model)
+    cold = cold_trainer.evaluate(valid_data)
+    assert cold_trainer.eval_warm == (0, 0) and cold == warm
+    config["hip_eval_hint"] = True
+
+
 @pytest.mark.parametrize("F", [384, 4096])
 def test_knn_graph_at_sports_item_count(F):
     """P6 at 18,357 items (config 3's frozen item-item graph, freedom.py:79-82): kNN(10) over row-normalised features on the

@@ -195,6 +195,7 @@ def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     def refusing(batch, k):
         raise MMRecHipError("score_topk: forced refusal")
     model.full_sort_topk = refusing
+    config["strict_fused_eval"] = False            # ... when the fallback is ALLOWED (round-5 review 8: no longer the default)
     t2b = Trainer(config, model)
     res_b = t2b.evaluate(valid_data)
     assert sizes and res_b == res
@@ -206,6 +207,24 @@ def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     t3 = Trainer(config, model)
     t3.evaluate(valid_data)
     assert t3.eval_path.startswith("fused")
+    # the default ('auto'): k > 128 is outside the tier -- the dense path, recorded ...
+    config["strict_fused_eval"] = "auto"
+    config["topk"] = [5, 70]
+    from mmrec_amd import hip_ops
+    kmax, hip_ops.TOPK_MAX = hip_ops.TOPK_MAX, 64  # (the 90-item fixture cannot rank 129 ids: lower the limit instead)
+    try:
+        t4 = Trainer(config, model)
+        t4.evaluate(valid_data)
+    finally:
+        hip_ops.TOPK_MAX = kmax
+    assert t4.eval_path.startswith("dense") and "max(topk)" in t4.eval_path
+    # ... while a refused shape OF THE TIER (tables 64 wide, k <= 128) raises instead of warning (round-5 review 8)
+    config["topk"] = [5, 70]
+    model.full_sort_topk = refusing
+    with pytest.raises(MMRecHipError, match="forced refusal"):
+        Trainer(config, model).evaluate(valid_data)
+    model.full_sort_topk = real_topk
+    valid_data.pr = 0                              # (a raising evaluation leaves the loader mid-iteration)
     config["strict_fused_eval"] = True             # (the raising evaluations come last: they leave the loader mid-iteration)
     config["topk"] = [5, 200]
     with pytest.raises(RuntimeError, match="strict_fused_eval"):
@@ -215,6 +234,65 @@ def test_evaluate_dense_fallback_is_batched_and_serves_any_k(tmp_path, golden):
     with pytest.raises(MMRecHipError):             # the kernel says no, and strict mode lets it
         Trainer(config, model).evaluate(valid_data)
     model.full_sort_topk = real_topk
+
+
+def test_warm_evaluation_state_machine(tmp_path, golden, monkeypatch):
+    """Round-5 review, next 1 (`hip_eval_hint`, models/_base.py): WHICH evaluation batches hand the fused kernel a hint.  The first
+    pass over a loader is cold and stores its lists; the TEST pass after the VALID pass and every later evaluation are warm
+    (hint rows = the users, the lists the previous pass produced); a pass whose warm queries crowd the overflow / slow queues
+    makes the next evaluation's first pass cold again while its second pass -- same tables -- stays warm; `hip_eval_hint:
+    False` never passes a hint; metrics never depend on any of it (the stand-in op ignores the hint, as the kernel's result does)."""
+    import torch
+    from mmrec_amd import hip_ops
+    from mmrec_amd.common.trainer import Trainer
+    config, train_data, valid_data, model = G.build(tmp_path, golden, "LightGCN", {"n_layers": 2, "reg_weight": 1e-4})
+    calls = []
+    real = hip_ops.score_topk
+
+    def spy(Q, C, k, rp=None, col=None, return_values=False, use_filter=True, hint=None, hint_rows=None, queue_counts=None):
+        calls.append(None if hint is None else (tuple(hint.shape), hint_rows.clone(), int((hint[hint_rows] >= 0).all())))
+        if hint is not None and spy.crowd:
+            queue_counts += torch.tensor([Q.shape[0], 0], dtype=torch.int32)
+        return real(Q, C, k, rp, col, return_values=return_values)
+    spy.crowd = False
+    monkeypatch.setattr(hip_ops, "score_topk", spy)
+    monkeypatch.setattr(hip_ops, "topk_hint_served", lambda nc, kd, k: True)
+    trainer = Trainer(config, model)
+    k = max(config["topk"])
+    first = trainer.evaluate(valid_data)
+    n_batches = len(calls)
+    assert n_batches >= 1 and all(c is None for c in calls) and trainer.eval_warm == (0, n_batches)
+    calls.clear()
+    second = trainer.evaluate(valid_data)            # the same users again (the TEST pass of the pair): every batch warm
+    assert second == first and trainer.eval_warm == (n_batches, 0)
+    assert all(c is not None and c[0] == (model.n_users, k) and c[2] == 1 for c in calls)
+    users = torch.cat([c[1] for c in calls])
+    assert torch.equal(users.cpu(), torch.as_tensor(valid_data.eval_u).long()[:users.numel()])
+    model.train(), model.eval()                      # new tables (a training epoch happened): still warm, from the old lists
+    calls.clear(), trainer.evaluate(valid_data)
+    assert trainer.eval_warm == (n_batches, 0)
+    spy.crowd = True                                 # ... but now the warm queries crowd the queues: the lists are stale
+    model.train(), model.eval()
+    calls.clear(), trainer.evaluate(valid_data)
+    assert trainer.eval_warm == (n_batches, 0) and model._hint["cold_from"] == model._tables_version + 1
+    spy.crowd = False
+    calls.clear(), trainer.evaluate(valid_data)      # same tables as the pass that wrote the lists: warm (TEST after VALID)
+    assert trainer.eval_warm == (n_batches, 0)
+    model.train(), model.eval()
+    calls.clear(), trainer.evaluate(valid_data)      # next evaluation: cold once, refreshing the lists ...
+    assert trainer.eval_warm == (0, n_batches) and all(c is None for c in calls)
+    calls.clear(), trainer.evaluate(valid_data)      # ... then warm again
+    assert trainer.eval_warm == (n_batches, 0) and model._hint["cold_from"] == model._tables_version
+    model.train(), model.eval()
+    calls.clear(), trainer.evaluate(valid_data)      # the refreshed lists serve the next tables without crowding: demand lifted
+    assert trainer.eval_warm == (n_batches, 0) and model._hint["cold_from"] == 0
+    config["hip_eval_hint"] = False
+    t2 = Trainer(config, model)
+    calls.clear()
+    assert t2.evaluate(valid_data) == first and all(c is None for c in calls) and t2.eval_warm == (0, 0)
+    config["hip_eval_hint"] = True
+    Trainer(config, model)
+    assert model.eval_hint is True
 
 
 def test_adjacent_id_tables_layout(tmp_path, golden):

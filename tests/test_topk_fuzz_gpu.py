@@ -20,6 +20,10 @@ rule: ids may differ from the oracle's only where the float64 score is within fp
 of masked ids (which only fill a tail when fewer than k candidates are unmasked, at exactly -1e10 like the reference).
 A failing case prints its seed: `pytest tests/test_topk_fuzz_gpu.py -k "seed17]"` re-runs it.
 
+Every case the fp16 filter serves is then ranked three more times as a WARM call (mmrec_score_topk_hinted_f32: threshold from a
+caller-supplied list, one matrix-core pass) with the cold call's own lists, a stale ranking read through `hint_rows`, and lists
+full of unusable ids: ids and values must equal the cold call's bit for bit (`hint_variants`).
+
 tests/test_topk_fuzz_cpu.py runs generator + checker on scaled-down cases against the torch-CPU stand-in op."""
 import numpy as np
 import pytest
@@ -168,8 +172,60 @@ def check_case(ops, dev, case):
     nq = Q.shape[0]
     rp, col = ops.mask_to_csr(mask, nq, dev)
     Qt, Ct = torch.from_numpy(Q), torch.from_numpy(C)
-    idx, val = ops.score_topk(Qt.to(dev), Ct.to(dev), k, rp, col, return_values=True)
+    Qd, Cd = Qt.to(dev), Ct.to(dev)
+    idx, val = ops.score_topk(Qd, Cd, k, rp, col, return_values=True)
     check_lists(describe(case), idx.cpu(), val.cpu(), Qt, Ct, mask, k)
+    check_warm_calls(ops, case, Qd, Cd, rp, col, idx, val)
+
+
+def hint_variants(case, idx):
+    """the lists a WARM call (mmrec_score_topk_hinted_f32) may be handed for this case, as (name, int32 [rows, hk], hint_rows):
+    the cold call's own output (the TEST pass after the VALID pass), a STALE ranking (the lists of perturbed tables: an earlier
+    epoch), and lists that bound nothing for some or all queries (-1 padding, out-of-range ids, duplicates, masked ids, random
+    ids) -- the result must be the cold call's bit for bit in every case."""
+    rng = np.random.default_rng(77 * case["seed"] + 5)
+    Q, C, k, nq, nc, mask = case["Q"], case["C"], case["k"], case["nq"], case["nc"], case["mask"]
+    out = [("own", idx.to(torch.int32).contiguous(), None)]
+    # stale: rankings of tables that moved (relative noise 0.3 on both sides), unmasked -- some ids are masked / low now
+    qs, cs = torch.from_numpy(Q), torch.from_numpy(C)
+    qn = qs + 0.3 * qs.abs().mean(dim=1, keepdim=True) * torch.from_numpy(rng.standard_normal(Q.shape).astype(np.float32))
+    cn = cs + 0.3 * cs.abs().mean(dim=1, keepdim=True) * torch.from_numpy(rng.standard_normal(C.shape).astype(np.float32))
+    hk = int(min(128, nc, k + int(rng.integers(0, 9))))
+    stale = torch.topk(torch.nan_to_num(qn @ cn.t()), hk, dim=1)[1].to(torch.int32)
+    # ... stored in a table with more rows than queries, read through hint_rows
+    table = torch.full((nq + 7, hk), -1, dtype=torch.int32)
+    rows = torch.from_numpy(rng.permutation(nq + 7)[:nq].astype(np.int64))
+    table[rows] = stale
+    out.append(("stale+rows", table, rows))
+    junk = idx.to(torch.int32).clone()
+    sel = torch.from_numpy(rng.random((nq, k)) < 0.3)
+    repl = torch.from_numpy(rng.integers(-3, nc + 3, (nq, k)).astype(np.int32))
+    junk[sel] = repl[sel]
+    if k > 1:
+        dup = torch.from_numpy(rng.random(nq) < 0.3)
+        junk[dup, -1] = junk[dup, 0]                       # a duplicate: the row has k - 1 usable ids
+    if mask.shape[1]:
+        m = torch.from_numpy(mask)
+        pick = torch.from_numpy(rng.integers(0, mask.shape[1], min(64, mask.shape[1])))
+        junk[m[0, pick], 0] = m[1, pick].to(torch.int32)   # a masked id heads the list
+    junk[torch.from_numpy(rng.random(nq) < 0.1)] = -1      # users without a list
+    out.append(("junk", junk, None))
+    return out
+
+
+def check_warm_calls(ops, case, Qd, Cd, rp, col, idx, val):
+    if not hasattr(ops, "topk_hint_served") or not ops.topk_hint_served(case["nc"], case["kd"], case["k"]) or case["nc"] < case["k"]:
+        return
+    dev = Qd.device
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    cands = ops.TopkCandidates(Cd)
+    for name, hint, rows in hint_variants(case, idx.cpu()):
+        widx, wval = ops.score_topk(Qd, cands if name != "junk" else Cd, case["k"], rp, col, return_values=True,
+                                    hint=hint.to(dev), hint_rows=None if rows is None else rows.to(dev), queue_counts=counts)
+        assert torch.equal(widx, idx), (describe(case), "warm call (%s hint): ids differ from the cold call" % name,
+                                        torch.nonzero((widx != idx).any(1)).flatten()[:4].tolist())
+        assert torch.equal(wval, val), (describe(case), "warm call (%s hint): values differ from the cold call" % name)
+    assert int(counts.min()) >= 0
 
 
 def check_lists(what, idx, val, Qt, Ct, mask, k, s64=None):

@@ -116,7 +116,53 @@ def main():
             dt = time.time() - t
             log("sharded=%s: %s evaluation of %d users in %.2fs (%.0f users/s incl. metrics), recall@20 %.4f" %
                 (sharded, which, valid_data.pr_end, dt, valid_data.pr_end / dt, res["recall@20"]))
-        if os.environ.get("MMREC_C5_DIAG"):                  # survivor statistics of the top-K filter on the embeddings just ranked
+        warm_steps = int(os.environ.get("MMREC_C5_WARM_STEPS", "0"))
+        if warm_steps:      # round 6: evaluation WARM -- TEST pass after VALID pass, then again after more training steps
+            log("sharded=%s: the second evaluation above ran warm/cold batches %s, queues (slow, overflow, warm queries) %s" %
+                (sharded, trainer.eval_warm, (model._hint or {}).get("last_queues")))
+            model.eval_hint = False                     # (the same Trainer: a second one would build a second optimizer)
+            for _ in range(2):
+                t = time.time()
+                res_c = trainer.evaluate(valid_data)
+                torch.cuda.synchronize()
+                dt = time.time() - t
+            log("sharded=%s: COLD evaluation (eval_hint off, same tables) in %.3fs (%.0f users/s), equal metrics: %s" %
+                (sharded, dt, valid_data.pr_end / dt, res_c == res))
+            model.eval_hint = True
+            u_old, i_old = [t.float().cpu().numpy() for t in model._cached_eval_embeddings()]
+            more = []
+            for b in train_data:
+                more.append(b)
+                if len(more) == warm_steps:
+                    break
+            trainer._train_epoch(more, 0)
+            torch.cuda.synchronize()
+            for which in ("first after %d more steps (lists of the previous tables)" % warm_steps, "second (TEST pass: fresh lists)"):
+                t = time.time()
+                res_w = trainer.evaluate(valid_data)
+                torch.cuda.synchronize()
+                dt = time.time() - t
+                log("sharded=%s: WARM evaluation, %s: %.3fs (%.0f users/s incl. metrics), warm/cold batches %s, queues (slow, "
+                    "overflow, warm queries) %s, recall@20 %.4f" % (sharded, which, dt, valid_data.pr_end / dt, trainer.eval_warm,
+                                                                     model._hint.get("last_queues"), res_w["recall@20"]))
+            model.eval_hint = False
+            t = time.time()
+            res_c = trainer.evaluate(valid_data)
+            torch.cuda.synchronize()
+            log("sharded=%s: COLD evaluation of the same tables: %.3fs, equal metrics: %s" % (sharded, time.time() - t, res_c == res_w))
+            model.eval_hint = True
+            if os.environ.get("MMREC_C5_DIAG"):
+                sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                from topk_survivor_model import survivor_stats, warm_survivor_stats
+                ue, ie = [t.float().cpu().numpy() for t in model._cached_eval_embeddings()]
+                rs = np.random.default_rng(0).choice(model.n_users, 256, replace=False)
+                inter = model.interaction_matrix.tocsr() if hasattr(model.interaction_matrix, "tocsr") else None
+                lists = [inter.indices[inter.indptr[u]:inter.indptr[u + 1]] for u in rs]
+                deg = np.array([len(l) for l in lists])
+                survivor_stats(ue[rs], ie, deg, tag="[c5] diag after %d steps, cold: " % warm_steps)
+                warm_survivor_stats(ue[rs], ie, u_old[rs], i_old, lists, tag="[c5] diag after %d steps, lists of the previous tables, " % warm_steps)
+                warm_survivor_stats(ue[rs], ie, ue[rs], ie, lists, tag="[c5] diag, lists of the SAME tables (TEST after VALID), ")
+        if os.environ.get("MMREC_C5_DIAG") and not warm_steps:   # survivor statistics of the top-K filter on the embeddings just ranked
             sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
             from topk_survivor_model import survivor_stats
             ue, ie = model._cached_eval_embeddings() if hasattr(model, "_cached_eval_embeddings") else model.eval_embeddings()

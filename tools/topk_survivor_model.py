@@ -71,6 +71,43 @@ def survivor_stats(U, I, m_per_query, k=50, tag="", clip=True):
                   (surv > 256).mean(), (surv > 512).mean(), low / U.shape[0]))
 
 
+def warm_survivor_stats(U, I, U_old, I_old, mask_lists, k=50, tag=""):
+    """Round 6: survivors of a WARM call (mmrec_score_topk_hinted_f32).  The threshold of query q is B = the smallest
+    approximate score, under the CURRENT tables (U, I), of the k unmasked ids that ranked top under the tables of the PREVIOUS
+    evaluation (U_old, I_old); survivors = candidates within 2 eps below B (+ the clipped rows).  U_old is U for the TEST pass
+    after the VALID pass.  mask_lists[q]: the query's masked ids.  Prints the same line as survivor_stats for comparison."""
+    ni = I.shape[0]
+    mean = I.mean(0)
+    Ic = I - mean
+    cn = np.linalg.norm(Ic, axis=1)
+    cmax = cn.max()
+    tau, n_out = clip_threshold(cn) if ni >= 131072 else (np.inf, 0)
+    out = cn >= tau
+    if n_out:
+        Ic = Ic * np.minimum(1.0, tau / np.maximum(cn, 1e-30))[:, None]
+    cm = min(cmax, tau)
+    surv, plain, low, kept = [], [], 0, []
+    for q in range(U.shape[0]):
+        s_old = I_old @ U_old[q]
+        s_old[mask_lists[q]] = -np.inf
+        hint = np.argpartition(-s_old, k - 1)[:k]
+        s = Ic @ U[q]
+        qn = np.linalg.norm(U[q])
+        eps = qn * (1.0e-3 * cm + 4e-6 * (cmax + np.linalg.norm(mean))) + 2.4e-7 * (qn + cm)
+        B = s[hint].min()
+        low += B < eps
+        surv.append(int(((s >= B - 2 * eps) | out).sum()))
+        plain.append(int((s >= B).sum()))
+        s_m = s.copy()
+        s_m[mask_lists[q]] = -np.inf
+        kept.append(len(np.intersect1d(np.argpartition(-s_m, k - 1)[:k], hint)))
+    surv, plain = np.array(surv), np.array(plain)
+    print("%swarm: survivors median %d p90 %d p99 %d max %d (without the 2 eps margin: median %d); > 256: %.3f  > 512: %.3f  > 1024 "
+          "(overflow queue's list): %.3f; B < eps (slow queue when rows are clipped): %.3f; ids of the old list still in the top-%d: "
+          "median %d" % (tag, np.median(surv), np.percentile(surv, 90), np.percentile(surv, 99), surv.max(), np.median(plain),
+                         (surv > 256).mean(), (surv > 512).mean(), (surv > 1024).mean(), low / U.shape[0], k, np.median(kept)))
+
+
 def main(shape):
     nu, ni, eu, ei = synth.shaped_edges(shape, seed=0)
     r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
