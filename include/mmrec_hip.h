@@ -285,25 +285,31 @@ int mmrec_score_topk_prepared_f32(const float* Q, const float* C, const void* pr
                                   int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
                                   int64_t* out_idx, float* out_val, void* workspace, int32_t flags,
                                   mmrec_stream_t stream);
-/* WARM evaluation (ABI 12): the same ranking with the filter's threshold taken from a caller-supplied list instead of a first
- * pass over all products -- ONE matrix-core pass per call instead of two.
+/* WARM evaluation (ABI 12): the same ranking with the filter's threshold taken from a per-query LIST instead of a first pass
+ * over all products -- ONE matrix-core pass per call instead of two.
  * replaces: the second and later runs of common/trainer.py:298-310 over the same users: the TEST pass that follows the VALID
  *           pass on the same frozen tables with the same train-positive mask (trainer.py:262,271; utils/dataloader.py:347,
  *           370-391), and every later epoch's evaluation, whose rankings move little from the previous one's.
- * hint [.., hint_k] int32: per query a list of candidate ids expected to rank high (typically the out_idx row a previous call
- * produced for that user), k <= hint_k <= MMREC_TOPK_MAX; hint_rows (int64 [nq], may be NULL): query q reads hint row
- * hint_rows[q] (NULL: row q).  Any k DISTINCT, UNMASKED, in-range ids of the row bound the k-th best score from below; their
- * approximate scores under the CURRENT Q and C give the threshold (topk_filter.hip: filter_hint_bound_kernel), so the output
- * is the exact top-k for ANY hint -- bit-identical to mmrec_score_topk_f32's: a stale list only lets more candidates through
- * to the exact refinement, a row with fewer than k usable ids (-1 padding, duplicates, masked ids) sends its query to the
- * exact slow queue.  queue_counts (int32 [2] on the device, may be NULL): the call ADDS the number of queries the slow queue
- * / the overflow queue served, so that a caller can return to the cold call when its lists have gone stale.
+ * hint [.., hint_k] int32, IN / OUT, k <= hint_k <= MMREC_TOPK_MAX (64 is the natural width for k <= 64, 128 above); hint_rows
+ * (int64 [nq], may be NULL): query q uses hint row hint_rows[q] (NULL: row q) -- e.g. a table with one row per user.
+ *   IN : candidate ids expected to rank high.  Any k DISTINCT, UNMASKED, in-range ids of the row bound the k-th best score from
+ *        below; their approximate scores under the CURRENT Q and C give the threshold (topk_filter.hip:
+ *        filter_hint_bound_kernel; with more than k usable ids the k-th largest), so the output is the exact top-k for ANY
+ *        list -- bit-identical to mmrec_score_topk_f32's: a stale list only lets more candidates through to the exact
+ *        refinement, a row with fewer than k usable ids (-1 padding, duplicates, masked ids) sends its query to the exact slow
+ *        queue.  flags & MMREC_TOPK_HINT_COLD: the row is not read (the call runs the two-pass form) -- the FIRST evaluation.
+ *   OUT: the call's own ranking of the query -- its top-k followed by the runners-up the refinement ranked anyway (up to
+ *        hint_k ids, -1 beyond) -- ready to be the next call's list; flags & MMREC_TOPK_HINT_KEEP leaves the row untouched.
+ * queue_counts (int32 [2] on the device, may be NULL): the call ADDS the number of queries the slow queue / the overflow queue
+ * served, so that a caller can return to the cold call when its lists have gone stale.
  * prepared: as for mmrec_score_topk_prepared_f32, or NULL (the call prepares C itself).  Served shapes: those of the fp16
- * filter (kd = 64 / 128, 4096 <= nc <= 1,000,000, k <= 128); others: MMREC_ERR_UNSUPPORTED.  flags must be 0.
+ * filter (kd = 64 / 128, 4096 <= nc <= 1,000,000, k <= 128); others: MMREC_ERR_UNSUPPORTED.  Other flag bits: MMREC_ERR_BAD_ARG.
  * workspace: mmrec_topk_workspace_bytes. */
+#define MMREC_TOPK_HINT_COLD 1
+#define MMREC_TOPK_HINT_KEEP 2
 int mmrec_score_topk_hinted_f32(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
                                 int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
-                                const int32_t* hint, int32_t hint_k, const int64_t* hint_rows,
+                                int32_t* hint, int32_t hint_k, const int64_t* hint_rows,
                                 int64_t* out_idx, float* out_val, void* workspace, int32_t* queue_counts,
                                 int32_t flags, mmrec_stream_t stream);
 

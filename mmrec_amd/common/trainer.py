@@ -82,6 +82,10 @@ class Trainer(AbstractTrainer):
         # process default hip_ops.*_DEFAULT -- so that a later Trainer of the same process (a hyper-parameter sweep,
         # quick_start's loop) never inherits the previous run's choice.  A caller who wants a mode without a config key sets the
         # DEFAULT (`hip_ops.DETERMINISTIC_DEFAULT = True`); the effective modes are logged.
+        how = config['reorder']
+        if how and str(how).lower() not in ('none', 'false', 'off') and getattr(model, 'relabelling', None) is None:
+            self.logger.warning('config `reorder: %s` is set but %s keeps its tables in the dataset\'s id order (the key is '
+                                'implemented by the plugins with RelabelledIdsMixin): ignored' % (how, type(model).__name__))
         from mmrec_amd import hip_ops
         hip_ops.set_deterministic(hip_ops.DETERMINISTIC_DEFAULT if config['hip_deterministic'] is None
                                   else bool(config['hip_deterministic']))

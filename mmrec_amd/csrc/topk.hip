@@ -762,12 +762,14 @@ extern "C" int mmrec_score_topk_prepared_f32(const float* Q, const float* C, con
 
 extern "C" int mmrec_score_topk_hinted_f32(const float* Q, const float* C, const void* prepared, int32_t nq, int32_t nc,
                                            int32_t kd, const int32_t* mask_rowptr, const int32_t* mask_col, int32_t k,
-                                           const int32_t* hint, int32_t hint_k, const int64_t* hint_rows,
+                                           int32_t* hint, int32_t hint_k, const int64_t* hint_rows,
                                            int64_t* out_idx, float* out_val, void* workspace, int32_t* queue_counts,
                                            int32_t flags, mmrec_stream_t stream) {
-    if (!hint || hint_k < k || hint_k > MMREC_TOPK_MAX || flags != 0) return MMREC_ERR_BAD_ARG;
+    if (!hint || hint_k < k || hint_k > MMREC_TOPK_MAX || (flags & ~(MMREC_TOPK_HINT_COLD | MMREC_TOPK_HINT_KEEP))) return MMREC_ERR_BAD_ARG;
     if (nq > 0 && nc > 0 && !topk64_filter_applicable(nq, nc, kd, k)) return MMREC_ERR_UNSUPPORTED;
     FilterHint h;
     h.ids = hint; h.hk = hint_k; h.rows = hint_rows; h.queue_counts = queue_counts;
+    h.cold = (flags & MMREC_TOPK_HINT_COLD) != 0;
+    h.update = (flags & MMREC_TOPK_HINT_KEEP) == 0;
     return score_topk_impl(Q, C, prepared, nq, nc, kd, mask_rowptr, mask_col, k, out_idx, out_val, workspace, 0, stream, h);
 }

@@ -9,14 +9,16 @@ size_t topk64_filter_workspace_bytes(int nq, int nc, int kd, int k);
 // candidate-side preparation (column statistics + centred fp16 copy of C), reusable across calls on the same C
 size_t topk64_filter_prepared_bytes(int nc, int kd);
 int topk64_filter_prepare(const float* C, int nc, int kd, void* prepared, hipStream_t s);
-// A WARM call's extras (mmrec_score_topk_hinted_f32): per query a list of `hk` candidate ids expected to rank high (row
-// rows[q] of `ids`, or row q when rows is null) from which the threshold is taken without pass 1; queue_counts (nullable):
-// [2] device counters the call ADDS its slow-queue / overflow-queue lengths to.  ids == nullptr: the cold two-pass call.
+// A call with per-query LISTS (mmrec_score_topk_hinted_f32): row rows[q] of `ids` (row q when rows is null), `hk` ids wide.
+// !cold: the threshold is taken from the list instead of pass 1 (a warm call); update: the call leaves its ranking (top-k and the
+// runners-up it ranked, -1 padded) in the row for the next one.  queue_counts (nullable): [2] device counters the call ADDS its
+// slow-queue / overflow-queue lengths to.  ids == nullptr: a plain call.
 struct FilterHint {
-    const int32_t* ids = nullptr;
+    int32_t* ids = nullptr;
     int hk = 0;
     const int64_t* rows = nullptr;
     int* queue_counts = nullptr;
+    bool cold = false, update = true;
 };
 // same contract as mmrec_score_topk_f32 (kd == 64 or 128): enqueues on `s`, never synchronises; `prepared` may be null
 int topk64_filter_launch(const float* Q, const float* C, int nq, int nc, int kd, const int32_t* mask_rowptr,

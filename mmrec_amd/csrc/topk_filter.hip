@@ -569,27 +569,34 @@ __global__ __launch_bounds__(256, (MMREC_TF_OCC3 && FILTER && SPARSE && KB == 1)
 // scores: fp16 rounding of both operands (2u + u^2 and
 // the accumulation, 1.0e-3 of |q| max|c'|) plus the fp32 rounding of the EXACT scores the final kernel ranks by
 // (kd * 2^-24 of |q| max|c|, the uncentred norm: |c| <= |c'| + |mean|)
-__device__ __forceinline__ void filter_eps_store(float B, int q, int lane, int nc, int kd, const float* __restrict__ qnorm,
-                                                 const unsigned* __restrict__ cmax_key, const float* __restrict__ stats,
-                                                 float* __restrict__ thr, int* __restrict__ flag) {
+__device__ __forceinline__ float filter_eps(int q, int nc, int kd, const float* __restrict__ qnorm,
+                                            const unsigned* __restrict__ cmax_key, const float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
     float mu = 0.f;
     for (int c = lane; c < kd; c += 64) {
         const float mc = stats[c] / (float)nc;
         mu = fmaf(mc, mc, mu);
     }
     mu = wave_sum(mu);
+    const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
+    const float cmax = key2f(*cmax_key);
+    const float kb = (float)kd * (1.f / 64.f);
+    // + 2^-25 sqrt(kd) (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
+    // (sum |x_i| <= sqrt(kd) |x|; 2.4e-7 = 2^-22 for kd = 64)
+    const bool clipped = reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
+    const float cmax0 = clipped ? key2f(reinterpret_cast<const unsigned*>(stats)[ST_NMAX0]) : cmax;   // before clipping
+    return qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax0 + sc * sqrtf(mu))) + 2.4e-7f * sqrtf(kb) * (qnorm[q] + cmax);
+}
+// need_nonneg: the cold path's bound may be a CLIPPED row's group maximum (stored score ~ f s, f < 1), which bounds that row's
+// real score from below only where it is >= eps; the warm path corrects clipped rows one by one and passes false.
+__device__ __forceinline__ void filter_eps_store(float B, int q, int lane, int nc, int kd, const float* __restrict__ qnorm,
+                                                 const unsigned* __restrict__ cmax_key, const float* __restrict__ stats,
+                                                 float* __restrict__ thr, int* __restrict__ flag, bool need_nonneg = true) {
+    const float eps = filter_eps(q, nc, kd, qnorm, cmax_key, stats);
     if (lane == 0) {
-        const float sc = fp16_scale(2.f * key2f(reinterpret_cast<const unsigned*>(stats)[ST_CMAX]));
-        const float cmax = key2f(*cmax_key);
-        const float kb = (float)kd * (1.f / 64.f);
-        // + 2^-25 sqrt(kd) (|q| + max|c'|): elements below fp16's normal range are rounded with absolute error 2^-25
-        // (sum |x_i| <= sqrt(kd) |x|; 2.4e-7 = 2^-22 for kd = 64)
         const bool clipped = reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
-        const float cmax0 = clipped ? key2f(reinterpret_cast<const unsigned*>(stats)[ST_NMAX0]) : cmax;   // before clipping
-        const float eps = qnorm[q] * (1.0e-3f * cmax + 4.0e-6f * kb * (cmax0 + sc * sqrtf(mu))) +
-                          2.4e-7f * sqrtf(kb) * (qnorm[q] + cmax);
         // clipped candidate rows are lower bounds of real scores only where the bound is >= eps
-        const bool ok = !clipped || B >= eps;
+        const bool ok = !need_nonneg || !clipped || B >= eps;
         thr[q] = ok ? B - 2.f * eps : INFINITY;
         flag[q] = ok ? 0 : 1;
     }
@@ -658,8 +665,14 @@ __global__ __launch_bounds__(256) void filter_bound_kernel(const unsigned* __res
 // this file, which never depended on the accumulation order), B = min_j a_j gives k unmasked candidates with exact score >=
 // B - eps, so every true top-k candidate has exact score >= B - eps and approximate score >= B - 2 eps =: thr -- the cold
 // path's argument with the (k + m)-th group maximum replaced by B (no "+ m": the listed ids are checked against the mask).
-// Clipped rows (large candidate sets): a listed clipped row's stored score approximates f s, f < 1; as in the cold path it is
-// a lower bound of s where B >= eps (filter_eps_store checks).  A STALE list only loosens thr (more survivors for the exact
+// More than k usable ids (the final kernel leaves the runners-up it ranked behind the top-k in the list: hk = 64 or 128): B = the
+// k-th LARGEST of their scores -- after the tables have moved the new top-k still sits inside the old top-64 long after it has
+// left the old top-k.
+// Clipped rows (large candidate sets): a listed clipped row is stored as f c', f = tau' / |c'| < 1, so its approximate score a
+// bounds f s: s >= (a - eps) / f (a - eps of either sign); it enters with B_j = (a - eps) / f + eps.  (Taking a itself, as the
+// cold path's group maxima must, cost every user whose list holds one of the <= 32 outlying items -- most users -- a bound far
+// below the k-th score: 16 % of a config-5 block in the overflow / slow queues, 82 ms instead of 6.)
+// A STALE list only loosens thr (more survivors for the exact
 // refinement, the overflow / slow queues beyond that); a list with fewer than k usable ids sends the query to the exact slow
 // queue: results never depend on the hint.  One wave per query; W = kd / 8 lanes per listed row (16-B fp16 chunks).
 template <int KB>
@@ -670,10 +683,12 @@ __global__ __launch_bounds__(256) void filter_hint_bound_kernel(const uint4* __r
                                                                 const int32_t* __restrict__ mask_col,
                                                                 const float* __restrict__ qnorm,
                                                                 const unsigned* __restrict__ cmax_key,
-                                                                const float* __restrict__ stats, float* __restrict__ thr,
-                                                                int* __restrict__ flag) {
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ cnorm,     // clipping sets: row norms
+                                                                float* __restrict__ thr, int* __restrict__ flag) {
     constexpr int W = 8 * KB, RPS = 64 / W;     // lanes per row, rows per wave step
     __shared__ int s_id[4][128];
+    __shared__ float s_val[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = blockIdx.x * 4 + wave;
     if (q >= nq) return;                        // waves are independent below (wave-level fences only)
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
@@ -729,17 +744,23 @@ __global__ __launch_bounds__(256) void filter_hint_bound_kernel(const uint4* __r
     float qf[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = (float)qh[j];
-    float bmin = INFINITY;
+    const bool clips = cnorm != nullptr && reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
+    const float tau = clips ? stats[ST_TAU] : INFINITY;
+    const float eps = filter_eps(q, nc, 64 * KB, qnorm, cmax_key, stats);
+    s_val[wave][lane] = -INFINITY;
+    s_val[wave][lane + 64] = -INFINITY;
     constexpr int NB = 4;                       // row steps in flight
     for (int e0 = 0; e0 < hk; e0 += RPS * NB) {
         int rid[NB];
         uint4 cv[NB];
+        float nrm[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int e = e0 + b * RPS + sub;
             rid[b] = e < hk ? s_id[wave][e] : -1;
             const int r = rid[b] >= 0 ? rid[b] : 0;
             cv[b] = Cs[(((size_t)(r >> 6) * KB + (ch >> 3)) * 64 + (r & 63)) * 8 + (ch & 7)];
+            nrm[b] = clips ? cnorm[r] : 0.f;
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -749,12 +770,32 @@ __global__ __launch_bounds__(256) void filter_hint_bound_kernel(const uint4* __r
             for (int j = 0; j < 8; ++j) a = fmaf(qf[j], (float)chv[j], a);
 #pragma unroll
             for (int o = W / 2; o >= 1; o >>= 1) a += __shfl_xor(a, o, W);
-            if (rid[b] >= 0) bmin = fminf(bmin, a);
+            if (nrm[b] >= tau) a = (a - eps) / (tau * (1.f - 1.f / 512.f) / nrm[b]) + eps;     // a clipped row: see above
+            if (rid[b] >= 0 && ch == 0) s_val[wave][e0 + b * RPS + sub] = a;
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) bmin = fminf(bmin, __shfl_xor(bmin, o, 64));
-    filter_eps_store(bmin, q, lane, nc, 64 * KB, qnorm, cmax_key, stats, thr, flag);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // the k-th largest of the usable rows' bounds (n_ok >= k of them are finite)
+    Cand y0 = Cand{s_val[wave][lane], lane}, y1 = Cand{s_val[wave][lane + 64], lane + 64};
+    bitonic128(y0, y1, lane);
+    const float B = k <= 64 ? __shfl(y0.v, k - 1, 64) : __shfl(y1.v, k - 65, 64);
+    filter_eps_store(B, q, lane, nc, 64 * KB, qnorm, cmax_key, stats, thr, flag, false);
+}
+
+// The lists of the queries the overflow / slow queues ranked (their kernels write out_idx only): top-k ids, -1 beyond.  One wave
+// per queue entry; an entry that sits in both queues is written twice with the same ids.
+__global__ __launch_bounds__(256) void filter_hint_from_out_kernel(const int* __restrict__ flist, const int* __restrict__ olist,
+                                                                   const int* __restrict__ n_flagged,
+                                                                   const int64_t* __restrict__ out_idx, int k,
+                                                                   int32_t* __restrict__ hint_out, int hk,
+                                                                   const int64_t* __restrict__ hint_rows) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = n_flagged[0], n1 = olist ? n_flagged[1] : 0;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n0 + n1; e += gridDim.x * 4) {
+        const int q = e < n0 ? flist[e] : olist[e - n0];
+        int32_t* hr = hint_out + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk;
+        for (int j = lane; j < hk; j += 64) hr[j] = j < k ? (int32_t)out_idx[(size_t)q * k + j] : -1;
+    }
 }
 
 // queue_counts[0] += queries the exact slow queue served, [1] += queries that went through the overflow queue (either is a
@@ -936,7 +977,8 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
     const int* __restrict__ outl,     // outl: nullptr, or {count, ids ...} of the clipped candidate rows (always rescored)
     int* __restrict__ olist,          // SPARSE: queue of the queries whose survivors do not fit CAP (filter_overflow_kernel);
                                       // its length is n_flagged[1]
-    int wcap) {                       // SPARSE: entries per query in wlist (>= CAP)
+    int wcap,                         // SPARSE: entries per query in wlist (>= CAP)
+    int32_t* __restrict__ hint_out, int hk, const int64_t* __restrict__ hint_rows) {   // warm calls' lists (nullptr: none kept)
     __shared__ unsigned long long s_l[4][CAP];   // (score, id) of the unmasked survivors
     __shared__ int s_ids[4][CAP];
     __shared__ int s_mask[4][F_MASK_LDS];
@@ -977,7 +1019,9 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
         // Through the slow queue each such query cost a 500K-candidate scan (0.4 ms per 65,536-query block at config 5).
         for (int e = lane; e < m; e += 64) s_mask[wave][e] = mask_col[m_lo + e];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (int j = lane; j < k; j += 64) {
+        int32_t* hr = hint_out ? hint_out + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk : nullptr;
+        for (int j = lane; j < max(k, hr ? hk : 0); j += 64) {
+            if (j >= k) { hr[j] = -1; continue; }
             int lo = 0, hi = m;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -985,6 +1029,7 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             }
             out_idx[(size_t)q * k + j] = (int64_t)(j + lo);
             if (out_val) out_val[(size_t)q * k + j] = 0.f;
+            if (hr) hr[j] = j + lo;
         }
         return;
     }
@@ -1092,6 +1137,13 @@ __global__ __launch_bounds__(256) void filter_final_kernel(
             if (64 + lane < k) {
                 out_idx[(size_t)q * k + 64 + lane] = (int64_t)y1.i;
                 if (out_val) out_val[(size_t)q * k + 64 + lane] = y1.v;
+            }
+            if (hint_out) {
+                // the next warm call's list: the top-k AND the runners-up this wave ranked anyway (ranks < 64, or < 128 for
+                // k > 64: sort_best_k), -1 beyond the survivors
+                int32_t* hr = hint_out + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk;
+                if (lane < hk) hr[lane] = lane < valid ? y0.i : -1;
+                if (64 + lane < hk) hr[64 + lane] = (k > 64 && 64 + lane < valid) ? y1.i : -1;
             }
         }
     }
@@ -1350,9 +1402,12 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
                        stats, Qs, qnorm, (unsigned*)nullptr, n_flagged, p.sparse ? wcnt : (int*)nullptr);
     PassArgs a{Qs, Cs, nq, nc, p.n_stages, p.spr, p.n_groups, p.p1_stride, p.wcap, gkeys, thr, bits, wcnt, wlist};
     const dim3 grid(p.qblocks, p.R);
-    if (hint.ids) {      // warm: the threshold from the caller's lists, no pass 1
-        hipLaunchKernelGGL(filter_hint_bound_kernel<KB>, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Qs, Cs, hint.ids, hint.hk, hint.rows,
-                           nq, nc, k, mask_rowptr, mask_col, qnorm, cmax, stats, thr, flag);
+    if (hint.ids && !hint.cold) {      // warm: the threshold from the caller's lists, no pass 1
+        const size_t n_pad = (size_t)p.n_stages * 64;
+        const float* cnorm = filter_clips(nc) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Cs) + al256f(n_pad * 2 * kd))
+                                              : (const float*)nullptr;
+        hipLaunchKernelGGL(filter_hint_bound_kernel<KB>, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Qs, Cs, (const int32_t*)hint.ids, hint.hk,
+                           hint.rows, nq, nc, k, mask_rowptr, mask_col, qnorm, cmax, stats, cnorm, thr, flag);
     } else {
         hipLaunchKernelGGL((filter_pass_kernel<false, false, KB>), grid, dim3(256), 0, s, a);
         hipLaunchKernelGGL(filter_bound_kernel, dim3(cdiv_i(nq, 4)), dim3(256), 0, s, gkeys, p.n_groups, nq, nc, k,
@@ -1363,15 +1418,16 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     else
         hipLaunchKernelGGL((filter_pass_kernel<true, false, KB>), grid, dim3(256), 0, s, a);
     if (MMREC_TF_PROBE & 32) MMREC_RETURN_LAUNCH_STATUS();   // probe: the two passes only
+    int32_t* hout = (hint.ids && hint.update) ? hint.ids : (int32_t*)nullptr;      // in place: read by the bound kernel above
     if (p.sparse && p.p1_stride >= 2)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP2>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap, hout, hint.hk, hint.rows);
     else if (p.sparse)
         hipLaunchKernelGGL((filter_final_kernel<true, KB, F_WCAP>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap, hout, hint.hk, hint.rows);
     else
         hipLaunchKernelGGL((filter_final_kernel<false, KB, F_CAPQ>), dim3(cdiv_i(nq, 4)), dim3(256), 0, s, Q, C, nq, nc, k, mask_rowptr,
-                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap);
+                           mask_col, bits, wcnt, wlist, p.R, 2 * p.spr, flag, flist, n_flagged, out_idx, out_val, outl, olist, p.wcap, hout, hint.hk, hint.rows);
     if (p.sparse)
         hipLaunchKernelGGL(filter_overflow_kernel<KB>, dim3(256), dim3(64 * F_SLOW_WAVES), 0, s, Q, C, nc, k, mask_rowptr, mask_col,
                            olist, n_flagged, wcnt, wlist, p.wcap, 2 * p.spr, outl, flist, out_idx, out_val);
@@ -1381,6 +1437,9 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     if (want > 1)
         hipLaunchKernelGGL(filter_slow_merge_kernel, dim3(64), dim3(256), 0, s, flist, n_flagged, want, parts, k, out_idx,
                            out_val);
+    if (hout)
+        hipLaunchKernelGGL(filter_hint_from_out_kernel, dim3(64), dim3(256), 0, s, flist, olist, n_flagged, out_idx, k, hout, hint.hk,
+                           hint.rows);
     if (hint.queue_counts)
         hipLaunchKernelGGL(filter_counts_add_kernel, dim3(1), dim3(1), 0, s, n_flagged, hint.queue_counts);
     MMREC_RETURN_LAUNCH_STATUS();

@@ -1105,16 +1105,26 @@ def topk_hint_served(nc, kd, k):
     return k <= TOPK_MAX and _lib.load().mmrec_topk_prepared_bytes(int(nc), int(kd)) > 0
 
 
+TOPK_HINT_COLD, TOPK_HINT_KEEP = 1, 2
+
+
+def topk_hint_width(k):
+    """natural width of a list table for top-k calls: the final kernel ranks 64 (k <= 64) or 128 survivors anyway"""
+    return 64 if k <= 64 else 128
+
+
 def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True, hint=None, hint_rows=None,
-               queue_counts=None):
+               queue_counts=None, hint_cold=False, hint_update=True):
     """top-k over candidates c of <Q[q], C[c]> per query with masked candidates at -1e10; never
     materialises the score matrix.  Returns int64 [nq, k] sorted by score desc (ties: lower id).
     C: a tensor, or a TopkCandidates (the candidate-side preparation of the fp16 filter done once for many calls).
     use_filter=False keeps the materialised fp32 path where the fp16 filter would serve the call (A/B measurements).
-    hint (int32 [rows, hk >= k], with hint_rows int64 [nq] or one row per query): a WARM call -- per query a list of ids
-    expected to rank high (a previous call's output for the same user); the filter takes its threshold from them and runs ONE
-    matrix-core pass instead of two.  The result does not depend on the hint (bit-identical to the cold call); shapes the
-    filter does not serve ignore it.  queue_counts (int32 [2], device): += queries the slow / overflow queues served."""
+    hint (int32 [rows, k <= hk <= 128], IN / OUT, with hint_rows int64 [nq] or one row per query): a WARM call -- per query a
+    list of ids expected to rank high (what a previous call left in the row for the same user); the filter takes its threshold
+    from them and runs ONE matrix-core pass instead of two, and (hint_update) leaves this call's ranking -- top-k + runners-up
+    -- in the row.  hint_cold: the rows are only written (the first evaluation).  The result does not depend on the hint
+    (bit-identical to the plain call); shapes the filter does not serve ignore it.  queue_counts (int32 [2], device): +=
+    queries the slow / overflow queues served."""
     lib = _lib.load()
     Q = _chk(Q.contiguous(), torch.float32, "Q", 2)
     prepared = None
@@ -1145,14 +1155,16 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
         if queue_counts is not None:
             _chk(queue_counts, torch.int32, "queue_counts", 1)
     if nq > 2 * TOPK_QUERY_BLOCK and use_filter and (prepared is not None or lib.mmrec_topk_prepared_bytes(nc, kd) > 0):
-        return _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values, hint, hint_rows, queue_counts)
+        return _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values, hint, hint_rows, queue_counts,
+                                   hint_cold, hint_update)
     idx = torch.empty(nq, k, dtype=torch.int64, device=Q.device)
     val = torch.empty(nq, k, dtype=torch.float32, device=Q.device) if return_values else None
     ws = _ws(lib.mmrec_topk_workspace_bytes(nq, nc, kd, k), Q.device)
     if hint is not None:
         _lib.check(lib.mmrec_score_topk_hinted_f32(_p(Q), _p(C), _p(prepared), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
                                                    _p(hint), hint.shape[1], _p(hint_rows), _p(idx), _p(val), _p(ws),
-                                                   _p(queue_counts), 0, _stream()), "score_topk_hinted")
+                                                   _p(queue_counts), (TOPK_HINT_COLD if hint_cold else 0) |
+                                                   (0 if hint_update else TOPK_HINT_KEEP), _stream()), "score_topk_hinted")
     elif prepared is not None:
         _lib.check(lib.mmrec_score_topk_prepared_f32(_p(Q), _p(C), _p(prepared), nq, nc, kd, _p(mask_rowptr), _p(mask_col), k,
                                                      _p(idx), _p(val), _p(ws), 0, _stream()), "score_topk_prepared")
@@ -1166,7 +1178,8 @@ def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, us
 TOPK_QUERY_BLOCK = 65536     # the Trainer's `hip_eval_batch_size`: 256 query blocks x 16 candidate ranges = 8 exact rounds of workgroups
 
 
-def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values, hint=None, hint_rows=None, queue_counts=None):
+def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values, hint=None, hint_rows=None, queue_counts=None,
+                        hint_cold=False, hint_update=True):
     """Very many queries in ONE call (a script ranking all 1M users at once): the fp16 filter's workspace is per query
     (~16 KB of word list at 500K candidates: 16 GB for 1M queries), so the call is walked in blocks of TOPK_QUERY_BLOCK queries
     against ONE preparation of the candidates -- what the Trainer's evaluation batches amount to.  One small device -> host
@@ -1190,7 +1203,8 @@ def _score_topk_blocked(Q, C, prepared, k, mask_rowptr, mask_col, return_values,
         h = hr = None
         if hint is not None:
             h, hr = (hint, hint_rows[a:b]) if hint_rows is not None else (hint[a:b], None)
-        out = score_topk(Q[a:b], cands, k, rp, col, return_values=return_values, hint=h, hint_rows=hr, queue_counts=queue_counts)
+        out = score_topk(Q[a:b], cands, k, rp, col, return_values=return_values, hint=h, hint_rows=hr, queue_counts=queue_counts,
+                         hint_cold=hint_cold, hint_update=hint_update)
         if return_values:
             idx[a:b], val[a:b] = out
         else:

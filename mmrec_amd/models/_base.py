@@ -104,8 +104,8 @@ class FusedEvalMixin:
     # products; a cold call gets it from a first pass over ALL products, a warm call from the k ids ranked for that user LAST
     # time -- the VALID pass's list when the TEST pass follows on the same frozen tables (trainer.py:262,271), the previous
     # epoch's list otherwise -- rescored under the current tables (mmrec_score_topk_hinted_f32): one matrix-core pass instead
-    # of two, the same exact top-k.  The lists live on the device ([n_users, k] int32, candidate ids as the kernel reports
-    # them); which users have one -- and under which evaluation tables it was written -- is tracked on the host, so a batch is
+    # of two, the same exact top-k.  The lists live on the device ([n_users, 64 or 128] int32: the top-k and the runners-up the
+    # kernel ranked anyway, written by the call itself, candidate ids as the kernel reports them); which users have one -- and under which evaluation tables it was written -- is tracked on the host, so a batch is
     # only ranked warm when every user of it has a list.
     eval_hint = True
     _hint = None
@@ -119,7 +119,8 @@ class FusedEvalMixin:
             return hip_ops.score_topk(q, cands, k, rowptr, cols)
         st = self._hint
         if st is None or st['k'] != k or st['nc'] != nc or st['table'].device != q.device:
-            st = self._hint = dict(k=k, nc=nc, table=torch.full((self.n_users, k), -1, dtype=torch.int32, device=q.device),
+            st = self._hint = dict(k=k, nc=nc, table=torch.full((self.n_users, hip_ops.topk_hint_width(k)), -1, dtype=torch.int32,
+                                                                device=q.device),
                                    ver=np.zeros(self.n_users, dtype=np.int64), cold_from=0, warm=0, cold=0, queries=0,
                                    counts=torch.zeros(2, dtype=torch.int32, device=q.device))
         cache = getattr(interaction, 'cache', None)
@@ -134,14 +135,12 @@ class FusedEvalMixin:
         # written under the CURRENT tables count (the TEST pass after a cold VALID pass), until a cold pass has refreshed them
         oldest = int(st['ver'][users_np].min()) if users_np.shape[0] else 0
         warm = oldest > 0 and (oldest >= st['cold_from'] or oldest == self._tables_version)
-        if warm:
-            out = hip_ops.score_topk(q, cands, k, rowptr, cols, hint=st['table'], hint_rows=users, queue_counts=st['counts'])
-            if oldest != self._tables_version:           # lists of EARLIER tables: the ones that can be stale
-                st['queries'] += users_np.shape[0]
-        else:
-            out = hip_ops.score_topk(q, cands, k, rowptr, cols)
+        # either way the call leaves its ranking (top-k + the runners-up it ranked) in the users' rows for the next one
+        out = hip_ops.score_topk(q, cands, k, rowptr, cols, hint=st['table'], hint_rows=users, hint_cold=not warm,
+                                 queue_counts=st['counts'] if warm else None)
+        if warm and oldest != self._tables_version:      # lists of EARLIER tables: the ones that can be stale
+            st['queries'] += users_np.shape[0]
         st['warm' if warm else 'cold'] += 1
-        st['table'][users] = out.to(torch.int32)
         st['ver'][users_np] = self._tables_version
         return out
 
@@ -181,6 +180,8 @@ class RelabelledIdsMixin:
         how = config['reorder']
         on = how and str(how).lower() not in ('none', 'false', 'off')
         self.relabelling = BipartiteRelabelling(base_graph, self.n_users, self.n_items, str(how).lower(), self.device) if on else None
+        if self.relabelling is not None:
+            self._register_relabelling_hooks()
         return self.relabelling
 
     def _to_relabelled_rows_(self, param, side):
@@ -209,27 +210,43 @@ class RelabelledIdsMixin:
             self.relabelling.to(dev)
         return out
 
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        rl = self.relabelling
-        if rl is not None:
-            prefix = kwargs.get('prefix', '')
-            for name, side in self.relabelled_tables.items():
-                k = prefix + name
-                if k in sd:                                # original row `old` = relabelled row perm[old]
-                    perm = rl.perm_u if side == 'u' else rl.perm_i
-                    sd[k] = sd[k].detach().index_select(0, perm.to(sd[k].device))
-        return sd
+    # state_dict() / load_state_dict() see ORIGINAL row order through two hooks registered on the model itself (round-5 advice:
+    # overriding the two methods only worked for the top-level module -- a parent's load_state_dict recurses through
+    # _load_from_state_dict and never calls a child's override, so a checkpoint round trip through any wrapper scrambled the
+    # tables).  Hooks run at any nesting depth with the right prefix, for the positional and the keyword call forms alike.
+    def _register_relabelling_hooks(self):
+        if getattr(self, '_relabelling_hooks', False):
+            return
+        self._relabelling_hooks = True
 
-    def load_state_dict(self, state_dict, *args, **kwargs):
-        rl = self.relabelling
-        if rl is not None:
-            state_dict = dict(state_dict)
-            for name, side in self.relabelled_tables.items():
-                if name in state_dict:                     # relabelled row `new` = original row inv[new]
+        def to_original(module, state_dict, prefix, local_metadata):
+            rl = module.relabelling
+            if rl is None:
+                return
+            for name, side in module.relabelled_tables.items():
+                k = prefix + name
+                if k in state_dict:                            # original row `old` = relabelled row perm[old]
+                    perm = rl.perm_u if side == 'u' else rl.perm_i
+                    state_dict[k] = state_dict[k].detach().index_select(0, perm.to(state_dict[k].device))
+
+        def to_relabelled(module, state_dict, prefix, *unused):
+            rl = module.relabelling
+            if rl is None:
+                return
+            for name, side in module.relabelled_tables.items():
+                k = prefix + name
+                if k in state_dict:                            # relabelled row `new` = original row inv[new]
                     inv = rl.inv_u if side == 'u' else rl.inv_i
-                    state_dict[name] = state_dict[name].index_select(0, inv.to(state_dict[name].device))
-        return super().load_state_dict(state_dict, *args, **kwargs)
+                    state_dict[k] = state_dict[k].index_select(0, inv.to(state_dict[k].device))
+
+        if hasattr(self, 'register_state_dict_post_hook'):
+            self.register_state_dict_post_hook(to_original)
+        else:
+            self._register_state_dict_hook(to_original)
+        if hasattr(self, 'register_load_state_dict_pre_hook'):
+            self.register_load_state_dict_pre_hook(to_relabelled)
+        else:
+            self._register_load_state_dict_pre_hook(to_relabelled, with_module=True)
 
 
 class AdjacentTablesMixin:

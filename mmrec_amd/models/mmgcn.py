@@ -97,6 +97,8 @@ class GCN(nn.Module):
 
 
 class MMGCN(FusedEvalMixin, GeneralRecommender):
+    graph_capturable = True       # the step is a fixed launch sequence (~300 launches): replayed as a hipGraph by default (hip_graph_step: auto)
+
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
         self.num_user, self.num_item = self.n_users, self.n_items

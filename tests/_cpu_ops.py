@@ -250,12 +250,28 @@ def topk_hint_served(nc, kd, k):
     return k <= 128 and kd in (64, 128) and 4096 <= nc <= 1000000
 
 
+def hint_served(C, Q, k):
+    from mmrec_amd import hip_ops
+    Ct = C.C if isinstance(C, TopkCandidates) else C
+    return hip_ops.topk_hint_served(Ct.shape[0], Q.shape[1], k) and Ct.shape[0] >= k
+
+
+def topk_hint_width(k):
+    return 64 if k <= 64 else 128
+
+
 def score_topk(Q, C, k, mask_rowptr=None, mask_col=None, return_values=False, use_filter=True, hint=None, hint_rows=None,
-               queue_counts=None):
-    """(a warm call's hint never changes the result: the stand-in checks its shape and ignores it)"""
+               queue_counts=None, hint_cold=False, hint_update=True):
+    """(a warm call's list never changes the result: the stand-in checks its shape, ignores its content and -- like the kernel --
+    leaves the call's top-k in the rows, -1 beyond)"""
     if hint is not None:
         assert hint.dtype == torch.int32 and hint.dim() == 2 and k <= hint.shape[1] <= 128
         assert (hint_rows is None and hint.shape[0] == Q.shape[0]) or (hint_rows.dtype == torch.int64 and hint_rows.numel() == Q.shape[0])
+        if hint_update and hint_served(C, Q, k):
+            out = score_topk(Q, C, k, mask_rowptr, mask_col)
+            rows = hint_rows if hint_rows is not None else torch.arange(Q.shape[0])
+            hint[rows] = -1
+            hint[rows, :k] = out.to(torch.int32)
     if isinstance(C, TopkCandidates):
         C = C.C
     _mat(Q, "Q"), _mat(C, "C", width=Q.shape[1])
@@ -308,7 +324,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "topk_hint_served", "TopkCandidates", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

@@ -626,3 +626,24 @@ def test_bf16_three_way_split_projection_gradient_claim():
     tiny = (rng.standard_normal(512) * 1e-36).astype(np.float32)
     t = split(tiny)
     assert np.max(np.abs(t[0] + t[1] + t[2] - tiny.astype(np.float64))) <= 2.0 ** -133
+
+
+def test_run_configs_did_not_regress():
+    """Round-5 review, next 2: MMGCN's training step once went 3.4 -> 9.5 ms per batch and no table showed it.  Every round
+    commits `profiles/rNN_run_configs.json` (tools/run_config.py tier --json: Trainer-level ms per batch of VBPR and the five
+    models north_star names, at their BASELINE shapes); this test fails when the newest file is more than 15 % slower than the
+    previous round's on any configuration both hold (box-to-box spread of one build is ~5 %)."""
+    import glob
+    import json
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    files = sorted(f for f in glob.glob(os.path.join(root, "r*_run_configs.json")) if re.search(r"r\d+_run_configs\.json$", f))
+    assert len(files) >= 2, "need two rounds of profiles/rNN_run_configs.json, found %s" % files
+    prev, cur = (json.load(open(f))["configs"] for f in files[-2:])
+    tier = {"c1", "c2", "c3", "c4", "lattice", "mmgcn"}
+    assert tier <= set(cur), "the newest run-config file lacks %s" % sorted(tier - set(cur))
+    worse = {k: (prev[k]["ms_per_batch"], cur[k]["ms_per_batch"]) for k in cur
+             if k in prev and cur[k]["ms_per_batch"] > 1.15 * prev[k]["ms_per_batch"]}
+    assert not worse, "ms per batch regressed by more than 15 %% (previous round, this round): %s" % worse
+    assert cur["mmgcn"]["ms_per_batch"] <= 3.4, cur["mmgcn"]         # the review's bar for the regression it found

@@ -249,11 +249,14 @@ def test_warm_evaluation_state_machine(tmp_path, golden, monkeypatch):
     calls = []
     real = hip_ops.score_topk
 
-    def spy(Q, C, k, rp=None, col=None, return_values=False, use_filter=True, hint=None, hint_rows=None, queue_counts=None):
-        calls.append(None if hint is None else (tuple(hint.shape), hint_rows.clone(), int((hint[hint_rows] >= 0).all())))
-        if hint is not None and spy.crowd:
+    def spy(Q, C, k, rp=None, col=None, return_values=False, use_filter=True, hint=None, hint_rows=None, queue_counts=None,
+            hint_cold=False, hint_update=True):
+        assert hint is not None and hint_update                 # every call of the evaluation leaves its lists behind ...
+        calls.append(None if hint_cold else (tuple(hint.shape), hint_rows.clone(), int((hint[hint_rows][:, :k] >= 0).all())))
+        if not hint_cold and spy.crowd:                         # ... and only a warm one reads them (and reports its queues)
             queue_counts += torch.tensor([Q.shape[0], 0], dtype=torch.int32)
-        return real(Q, C, k, rp, col, return_values=return_values)
+        assert (queue_counts is None) == hint_cold
+        return real(Q, C, k, rp, col, return_values=return_values, hint=hint, hint_rows=hint_rows, hint_cold=hint_cold)
     spy.crowd = False
     monkeypatch.setattr(hip_ops, "score_topk", spy)
     monkeypatch.setattr(hip_ops, "topk_hint_served", lambda nc, kd, k: True)
@@ -265,7 +268,7 @@ def test_warm_evaluation_state_machine(tmp_path, golden, monkeypatch):
     calls.clear()
     second = trainer.evaluate(valid_data)            # the same users again (the TEST pass of the pair): every batch warm
     assert second == first and trainer.eval_warm == (n_batches, 0)
-    assert all(c is not None and c[0] == (model.n_users, k) and c[2] == 1 for c in calls)
+    assert all(c is not None and c[0] == (model.n_users, 64) and c[2] == 1 for c in calls)
     users = torch.cat([c[1] for c in calls])
     assert torch.equal(users.cpu(), torch.as_tensor(valid_data.eval_u).long()[:users.numel()])
     model.train(), model.eval()                      # new tables (a training epoch happened): still warm, from the old lists
@@ -288,8 +291,8 @@ def test_warm_evaluation_state_machine(tmp_path, golden, monkeypatch):
     assert trainer.eval_warm == (n_batches, 0) and model._hint["cold_from"] == 0
     config["hip_eval_hint"] = False
     t2 = Trainer(config, model)
-    calls.clear()
-    assert t2.evaluate(valid_data) == first and all(c is None for c in calls) and t2.eval_warm == (0, 0)
+    monkeypatch.setattr(hip_ops, "score_topk", real)
+    assert t2.evaluate(valid_data) == first and t2.eval_warm == (0, 0)
     config["hip_eval_hint"] = True
     Trainer(config, model)
     assert model.eval_hint is True
@@ -403,6 +406,21 @@ def test_freedom_relabelled_id_space_is_the_same_model(tmp_path, golden, how):
         for k, v in b["model"].state_dict().items():
             assert torch.equal(v, a["model"].state_dict()[k]), k
         a["model"].eval(), b["model"].eval()
+        assert torch.equal(a["model"].full_sort_topk(a["batch"], 20), b["model"].full_sort_topk(b["batch"], 20))
+        # ... and through a PARENT module (round-5 advice: a wrapper's load_state_dict recurses through _load_from_state_dict and
+        # never called the model's own override; its state_dict(destination, prefix, keep_vars) call is positional)
+        wa, wb = torch.nn.ModuleDict({"net": a["model"]}), torch.nn.ModuleDict({"net": b["model"]})
+        sd_a, sd_b = wa.state_dict(), wb.state_dict()
+        assert list(sd_a) == list(sd_b) and all(k.startswith("net.") for k in sd_a)
+        for k in sd_a:
+            assert torch.equal(sd_a[k], sd_b[k]), k
+        pos = b["model"].state_dict(None, "x.", False)             # the positional call form
+        assert all(torch.equal(pos["x." + k[4:]], v) for k, v in sd_b.items())
+        again = {k: v * 1.5 for k, v in sd_a.items()}
+        wa.load_state_dict(again), wb.load_state_dict(again)
+        for k, v in wb.state_dict().items():
+            assert torch.equal(v, again[k]) and torch.equal(v, wa.state_dict()[k]), k
+        a["model"].eval(), b["model"].eval()                       # (load_state_dict dropped the cached evaluation tables)
         assert torch.equal(a["model"].full_sort_topk(a["batch"], 20), b["model"].full_sort_topk(b["batch"], 20))
 
 

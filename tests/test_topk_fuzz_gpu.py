@@ -219,13 +219,30 @@ def check_warm_calls(ops, case, Qd, Cd, rp, col, idx, val):
     dev = Qd.device
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     cands = ops.TopkCandidates(Cd)
+    k, nc = case["k"], case["nc"]
     for name, hint, rows in hint_variants(case, idx.cpu()):
-        widx, wval = ops.score_topk(Qd, cands if name != "junk" else Cd, case["k"], rp, col, return_values=True,
-                                    hint=hint.to(dev), hint_rows=None if rows is None else rows.to(dev), queue_counts=counts)
+        hd, rd = hint.to(dev), None if rows is None else rows.to(dev)
+        widx, wval = ops.score_topk(Qd, cands if name != "junk" else Cd, k, rp, col, return_values=True,
+                                    hint=hd, hint_rows=rd, queue_counts=counts)
         assert torch.equal(widx, idx), (describe(case), "warm call (%s hint): ids differ from the cold call" % name,
                                         torch.nonzero((widx != idx).any(1)).flatten()[:4].tolist())
         assert torch.equal(wval, val), (describe(case), "warm call (%s hint): values differ from the cold call" % name)
+        # the call left ITS ranking in the rows: the top-k, then runners-up (distinct, in range) or -1
+        left = (hd if rd is None else hd[rd]).long()
+        assert torch.equal(left[:, :k], idx), (describe(case), name, "the call's lists do not start with its top-k")
+        tail = left[:, k:]
+        if tail.shape[1]:
+            assert int(tail.min()) >= -1 and int(tail.max()) < nc
+            full = torch.where(left >= 0, left, -1 - torch.arange(left.shape[1], device=dev)[None, :])     # (-1s made distinct)
+            assert not (torch.sort(full, dim=1)[0].diff(dim=1) == 0).any(), (describe(case), name, "duplicate ids in a list")
     assert int(counts.min()) >= 0
+    # the FIRST evaluation: a cold call through the same entry point writes the lists a warm call then reads (64 / 128 wide)
+    wide = torch.full((case["nq"], 64 if k <= 64 else 128), -7, dtype=torch.int32, device=dev)
+    cidx = ops.score_topk(Qd, cands, k, rp, col, hint=wide, hint_cold=True)
+    assert torch.equal(cidx, idx) and torch.equal(wide[:, :k].long(), idx) and int(wide.min()) >= -1
+    kept = wide.clone()
+    widx = ops.score_topk(Qd, cands, k, rp, col, hint=wide, hint_update=False)
+    assert torch.equal(widx, idx) and torch.equal(wide, kept), (describe(case), "warm call from the cold call's lists / KEEP flag")
 
 
 def check_lists(what, idx, val, Qt, Ct, mask, k, s64=None):

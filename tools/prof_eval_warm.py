@@ -71,24 +71,33 @@ def block_case(tag, U, I, rp, col, timer):
     cands = hip_ops.TopkCandidates(I)
     cold = hip_ops.score_topk(U, cands, K, rp, col)
     counts = torch.zeros(2, dtype=torch.int32, device=U.device)
+    W = hip_ops.topk_hint_width(K)
     t = timer(lambda: hip_ops.score_topk(U, cands, K, rp, col))
     print("%s cold: %.3f ms (min %.3f max %.3f)  %.2f M users/s" % (tag, t[0], t[1], t[2], U.shape[0] / t[0] / 1e3), flush=True)
     for name, rel in (("same tables", 0.0), ("moved 2 %", 0.02), ("moved 10 %", 0.1), ("moved 30 %", 0.3)):
-        if rel == 0.0:
-            hint = cold.to(torch.int32)
-        else:
-            Un, In = moved(U, I, rel, 7)
-            hint = hip_ops.score_topk(Un, In, K, rp, col).to(torch.int32)
-            del Un, In
-        counts.zero_()
-        out = hip_ops.score_topk(U, cands, K, rp, col, hint=hint, queue_counts=counts)
-        q = counts.tolist()
-        same = bool(torch.equal(out, cold))
-        kept = float((hint.long().unsqueeze(2) == cold.unsqueeze(1)).any(2).float().sum(1).mean()) if U.shape[0] <= 70000 else float("nan")
-        t = timer(lambda: hip_ops.score_topk(U, cands, K, rp, col, hint=hint))
-        print("%s warm, lists of %s (%.1f of %d ids still ranked): %.3f ms (min %.3f max %.3f)  %.2f M users/s; slow queue %d, overflow "
-              "queue %d of %d; ids == cold: %s" % (tag, name, kept, K, t[0], t[1], t[2], U.shape[0] / t[0] / 1e3, q[0], q[1], U.shape[0], same),
-              flush=True)
+        # the lists a cold call over the (moved) tables leaves behind: its top-k + the runners-up it ranked
+        hint = torch.full((U.shape[0], W), -1, dtype=torch.int32, device=U.device)
+        Un, In = (U, I) if rel == 0.0 else moved(U, I, rel, 7)
+        hip_ops.score_topk(Un, In if rel else cands, K, rp, col, hint=hint, hint_cold=True)
+        del Un, In
+        for width in ((W, K) if rel in (0.0, 0.1) else (W,)):      # with / without the runners-up
+            h = hint if width == W else hint[:, :K].contiguous()
+            counts.zero_()
+            out = hip_ops.score_topk(U, cands, K, rp, col, hint=h, queue_counts=counts, hint_update=False)
+            q = counts.tolist()
+            same = bool(torch.equal(out, cold))
+            listed = float((h >= 0).sum(1).float().mean())
+            kept = (float((h[:, :K].long().unsqueeze(2) == cold.unsqueeze(1)).any(2).float().sum(1).mean())
+                    if U.shape[0] <= 70000 else float("nan"))
+            t = timer(lambda: hip_ops.score_topk(U, cands, K, rp, col, hint=h, hint_update=False))
+            print("%s warm, lists of %s, %d wide (%.1f ids listed, %.1f of the old top-%d still ranked): %.3f ms (min %.3f max %.3f)  "
+                  "%.2f M users/s; slow queue %d, overflow queue %d of %d; ids == cold: %s" %
+                  (tag, name, width, listed, kept, K, t[0], t[1], t[2], U.shape[0] / t[0] / 1e3, q[0], q[1], U.shape[0], same), flush=True)
+    hint = torch.full((U.shape[0], W), -1, dtype=torch.int32, device=U.device)
+    t = timer(lambda: hip_ops.score_topk(U, cands, K, rp, col, hint=hint, hint_cold=True))
+    print("%s cold through the hinted entry (writes the lists): %.3f ms" % (tag, t[0]), flush=True)
+    t = timer(lambda: hip_ops.score_topk(U, cands, K, rp, col, hint=hint))
+    print("%s warm, same tables, lists updated in place by every call: %.3f ms" % (tag, t[0]), flush=True)
 
 
 def main():

@@ -96,7 +96,8 @@ def setup(name, cd_extra=None, epochs=3, root=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=sorted(CONFIGS))
+    ap.add_argument("config", choices=sorted(CONFIGS) + ["tier"], help="a configuration, or `tier` (with --json): " + " ".join(TIER))
+    ap.add_argument("--json", help="write {config: ms_per_batch, eval users/s} to this file (profiles/rNN_run_configs.json)")
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--device-neg-sampling", action="store_true")
     ap.add_argument("--graph-step", action="store_true", help="replay the training step as a hipGraph (every model that does not opt out)")
@@ -121,28 +122,60 @@ def main():
         cd['hip_pull_batch_rows'] = False
     if args.fp32_linear:
         cd['hip_linear_split'] = False
-    config, train_data, valid_data, test_data, model, _ = setup(args.config, cd, args.epochs)
+    if args.json:
+        names = TIER if args.config == "tier" else [args.config]
+        out = {n: run(n, cd, args.epochs) for n in names}
+        import json
+        with open(args.json, "w") as f:
+            json.dump({"what": "Trainer-level ms per training batch (best of epochs >= 1) and evaluation users/s (valid + test, metrics "
+                               "included) on synthetic data of each configuration's dataset shape, default settings, one MI355X",
+                       "epochs": args.epochs, "configs": out}, f, indent=1)
+        return
+    run(args.config, cd, args.epochs)
+
+
+# BASELINE.json's configurations: VBPR and the five models north_star names, at their shapes (the regression guard of
+# tests/test_host_logic.py::test_run_configs_did_not_regress compares profiles/rNN_run_configs.json of consecutive rounds)
+TIER = ["c1", "c2", "c3", "c4", "lattice", "mmgcn"]
+
+
+def run(name, cd=None, epochs=3, verbose=True):
+    """-> {"model", "dataset", "ms_per_batch" (best epoch after the first), "ms_per_batch_epochs", "eval_users_per_s", "step_mode"}"""
+    import shutil
+    config, train_data, valid_data, test_data, model, root = setup(name, cd, epochs)
     from mmrec_amd.common.trainer import Trainer
     trainer = Trainer(config, model)
     n_eval = valid_data.pr_end + test_data.pr_end
-    for epoch in range(args.epochs):
+    per_epoch, eval_rate = [], []
+    for epoch in range(epochs):
         t0 = time.time()
         model.pre_epoch_processing()
         loss, _ = trainer._train_epoch(train_data, epoch)
         torch.cuda.synchronize()
         t1 = time.time()
         valid = trainer.evaluate(valid_data)
+        warm_v = trainer.eval_warm
         test = trainer.evaluate(test_data)
         torch.cuda.synchronize()
         t2 = time.time()
-        print("[%s] epoch %d: train %.3fs (%d batches, %.2f ms/batch, loss %.4f) | eval valid+test %.3fs "
-              "(%.0f users/s incl. metrics) | valid recall@20 %.4f ndcg@20 %.4f | test recall@20 %.4f" %
-              (args.config, epoch, t1 - t0, len(train_data), (t1 - t0) / len(train_data) * 1e3, loss,
-               t2 - t1, n_eval / (t2 - t1), valid["recall@20"], valid["ndcg@20"], test["recall@20"]), flush=True)
+        per_epoch.append((t1 - t0) / len(train_data) * 1e3)
+        eval_rate.append(n_eval / (t2 - t1))
+        if verbose:
+            print("[%s] epoch %d: train %.3fs (%d batches, %.2f ms/batch, loss %.4f) | eval valid+test %.3fs "
+                  "(%.0f users/s incl. metrics; warm/cold batches valid %s test %s) | valid recall@20 %.4f ndcg@20 %.4f | test recall@20 %.4f" %
+                  (name, epoch, t1 - t0, len(train_data), per_epoch[-1], loss, t2 - t1, eval_rate[-1], warm_v, trainer.eval_warm,
+                   valid["recall@20"], valid["ndcg@20"], test["recall@20"]), flush=True)
     gs = getattr(trainer, '_graphed', None)
-    print("[%s] training step: %s" % (args.config, "eager (no graphed step)" if gs is None else
-                                      ("hipGraph capture FAILED -> eager" if gs.failed else "hipGraph replay")))
-    print("[%s] peak device memory %.2f GB" % (args.config, torch.cuda.max_memory_allocated() / 2 ** 30))
+    mode = "eager (no graphed step)" if gs is None else ("hipGraph capture FAILED -> eager" if gs.failed else "hipGraph replay")
+    if verbose:
+        print("[%s] training step: %s" % (name, mode))
+        print("[%s] peak device memory %.2f GB" % (name, torch.cuda.max_memory_allocated() / 2 ** 30))
+    model_name, ds, _ = CONFIGS[name]
+    del trainer, model, train_data, valid_data, test_data
+    torch.cuda.empty_cache()
+    shutil.rmtree(root, ignore_errors=True)
+    return {"model": model_name, "dataset": ds, "ms_per_batch": min(per_epoch[1:] or per_epoch), "ms_per_batch_epochs": per_epoch,
+            "eval_users_per_s": max(eval_rate[1:] or eval_rate), "step_mode": mode}
 
 
 if __name__ == "__main__":
