@@ -857,6 +857,165 @@ __global__ __launch_bounds__(512) void linear_bwd_w_bf16x3_kernel(const float* _
     }
 }
 
+// ---- Round 6: the same product with the dY side split ONCE PER CALL instead of once per workgroup ---------------------------
+// In the kernel above every one of the F / 128 column-block workgroups splits the same 32 x 64 dY tile again (a third of its VALU
+// work), through an LDS round trip (Gq -> registers -> Asp) that sits between the tile's barrier and its MFMAs, and the workgroups
+// with blockIdx.x == 0 also carry the bias gradient.  At 39 us for Amazon-Baby (X at 2.9 TB/s, MFMA pipe busy 30 %) nothing was
+// near a hardware limit: per 32-item tile a CU spent ~3,400 cycles where its MFMAs take 768 and its VALU work ~600 -- latency
+// chains between one barrier and the next, with a single 8-wave workgroup per CU to hide them.
+//   bwd_dy_split_kernel   dY -> the three bf16 parts of every tile, ALREADY in MFMA A-fragment layout (12 KB per 32-item tile,
+//                         [2 kstep + otile][part][lane] x 16 B: the old Asp image), + the bias gradient's partial sums;
+//   linear_bwd_w_v2       X tiles by LDS-DMA (3-stage ring) AND the ready-made A fragments by LDS-DMA (linear 12-KB copies: no
+//                         VALU, no LDS write, nothing between barrier and MFMAs but the X split); 72 KB of LDS, so TWO
+//                         workgroups share a CU and one's barrier wait runs under the other's MFMAs.
+// Same six products in the same order into the same accumulators as the kernel above: bit-identical dW; db's partial sums are
+// regrouped (per dy-split workgroup instead of per item chunk), fixed order, still free of atomics.
+#ifndef MMREC_BWD_W_V2
+#define MMREC_BWD_W_V2 1        // 0: the round-5 kernel (A/B: tools/prof_linear.py build-variants v1=-DMMREC_BWD_W_V2=0)
+#endif
+#ifndef MMREC_BWD_W2_AS
+#define MMREC_BWD_W2_AS 2       // A-fragment tiles in the LDS ring (2: issued one tile ahead; 3: two ahead, 84 KB = one workgroup per CU)
+#endif
+#ifndef MMREC_BWD_W2_OCC
+#define MMREC_BWD_W2_OCC 2      // workgroups per CU the kernel is compiled for (waves per SIMD = 2 x this)
+#endif
+constexpr int BW2_ATILE = 12 * 64 * 16;      // bytes of a tile's split dY fragments
+
+// grid: min(#tiles, 256) workgroups of 4 waves; workgroup g takes tiles g, g + G, ...; wave w = fragment (kstep = w >> 1, otile = w & 1).
+__global__ __launch_bounds__(256) void bwd_dy_split_kernel(const float* __restrict__ dY, int n, g_bf8* __restrict__ Asp_g,
+                                                          float* __restrict__ dbpart) {
+    __shared__ float s_db[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int n_tiles = (n + BW_BK - 1) / BW_BK;
+    float dbacc = 0.f;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int item0 = t * BW_BK + 16 * (wave >> 1) + 8 * h;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = item0 + e < n ? dY[(size_t)(item0 + e) * 64 + 32 * (wave & 1) + i] : 0.f;
+        g_bf8 p1, p2, p3;
+        split3(x, p1, p2, p3);
+        g_bf8* dst = Asp_g + (size_t)t * (12 * 64) + wave * 3 * 64 + lane;
+        dst[0] = p1;
+        dst[64] = p2;
+        dst[128] = p3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dbacc += x[e];
+    }
+    if (dbpart) {       // column o = 32 (wave & 1) + i: the partial sums of (kstep, h) in fixed order
+        s_db[wave][lane] = dbacc;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int ot = threadIdx.x >> 5, c = threadIdx.x & 31;
+            dbpart[blockIdx.x * 64 + threadIdx.x] = (s_db[ot][c] + s_db[ot][32 + c]) + (s_db[2 + ot][c] + s_db[2 + ot][32 + c]);
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(512, 2 * MMREC_BWD_W2_OCC) void linear_bwd_w_v2_kernel(const g_bf8* __restrict__ Asp_g,
+                                                                                    const float* __restrict__ X,
+                                                                                    float* __restrict__ part, int n, int F, int n_chunk) {
+    constexpr int S = 3, AS = MMREC_BWD_W2_AS;
+    __shared__ __attribute__((aligned(1024))) float Xr[S][BW_BK * BW_BF];      // X tiles [item][f], 3-stage ring (48 KB)
+    __shared__ __attribute__((aligned(1024))) g_bf8 Ar[AS][12 * 64];           // split dY fragments of a tile (12 KB each)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ft = wave & 3, ks = wave >> 2;
+    const int f0 = blockIdx.x * BW_BF;
+    const int nb = blockIdx.y * n_chunk, ne = min(nb + n_chunk, n);
+    const int rows = ne - nb;
+    const int T = (rows + BW_BK - 1) / BW_BK;
+    const i32x4 rx = raw_rsrc(X + (size_t)nb * F + f0, (unsigned)rows * (unsigned)F * 4u - (unsigned)f0 * 4u);
+    const i32x4 ra = raw_rsrc(reinterpret_cast<const char*>(Asp_g) + (size_t)(nb / BW_BK) * BW2_ATILE, (unsigned)T * (unsigned)BW2_ATILE);
+    int vx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) vx[j] = (2 * (2 * wave + j) + (lane >> 5)) * F * 4 + (lane & 31) * 16;
+    const int va = lane * 16;
+    // a tile's fragments are 12 linear 1-KB pieces: wave w brings piece w, waves 0-3 also piece 8 + w
+    auto issue_a = [&](int t) {
+        const unsigned dst = lds_addr(reinterpret_cast<const float*>(&Ar[t % AS][0]));
+        lds_dma16<false>(ra, dst + wave * 1024, va, t * BW2_ATILE + wave * 1024);
+        if (wave < 4) lds_dma16<false>(ra, dst + (8 + wave) * 1024, va, t * BW2_ATILE + (8 + wave) * 1024);
+    };
+    auto issue_x = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) lds_dma16<NT>(rx, lds_addr(&Xr[t % S][(2 * wave + j) * 256]), vx[j], t * BW_BK * F * 4);
+    };
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc0 = {0}, acc1 = {0};
+    auto compute = [&](int ab, int xb) {
+        const float* xr = Xr[xb] + (16 * ks + 8 * h) * BW_BF + 32 * ft + i;
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = xr[e * BW_BF];
+        const g_bf8* ap = &Ar[ab][(2 * ks) * 3 * 64 + lane];
+        const g_bf8 a1 = ap[0], a2 = ap[64], a3 = ap[128], c1 = ap[192], c2 = ap[256], c3 = ap[320];
+        g_bf8 b1, b2, b3;
+        split3(xv, b1, b2, b3);
+        // smallest products first, exactly as in the round-5 kernel
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b3, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, b2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b1, acc1, 0, 0, 0);
+    };
+    // vmcnt queue of a wave (AS = 2):  A(0) X(0) X(1) | A(1) X(2) | A(2) X(3) | ...   -- step t issues A(t + 1) BEFORE X(t + 2), so
+    // that "all but the two newest copies have landed" means X(t) and A(t) whatever a wave's number of A pieces.
+    // (AS = 3: A(0) A(1) X(0) X(1) | A(2) X(2) | ...: the newest 2 + nA copies may be in flight.)  Tiles past the end are issued
+    // too: out of the descriptors' range, they fill with zeros and are never multiplied.
+    if (T > 0) {
+        issue_a(0);
+        if (AS == 3) issue_a(1);
+        issue_x(0);
+        issue_x(1);
+    }
+    for (int t = 0; t < T; ++t) {
+        if (AS == 3) {
+            if (wave < 4) MMREC_WAIT_VM(4); else MMREC_WAIT_VM(3);
+        } else {
+            MMREC_WAIT_VM(2);
+        }
+        __builtin_amdgcn_s_barrier();       // everyone's pieces of tile t are in LDS; everyone has read tile t - 1
+        issue_a(t + AS - 1);
+        issue_x(t + 2);
+        compute(t % AS, t % S);
+    }
+    MMREC_WAIT_VM(0);      // (the zero-fill copies of the tiles past the end)
+    // the two k-step halves: waves 4-7 hand theirs over through LDS (the X ring is free now: 64 x 128 floats)
+    float* red = &Xr[0][0];
+    static_assert(S * BW_BK * BW_BF >= 64 * BW_BF, "the X ring holds the 64 x 128 hand-over tile");
+    __builtin_amdgcn_s_barrier();
+    if (ks == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = d_row(r, lane);
+            red[o * BW_BF + ft * 32 + i] = acc0[r];
+            red[(32 + o) * BW_BF + ft * 32 + i] = acc1[r];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ks == 0) {
+        float* dst = part + (size_t)blockIdx.y * 64 * F;
+        const int f = f0 + ft * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = d_row(r, lane);
+            dst[(size_t)o * F + f] = acc0[r] + red[o * BW_BF + ft * 32 + i];
+            dst[(size_t)(32 + o) * F + f] = acc1[r] + red[(32 + o) * BW_BF + ft * 32 + i];
+        }
+    }
+}
+
 // dX[n, F] = dY[n, 64] W[64, F] on v_mfma_f32_32x32x16_f16, the streaming form of gemm64_stream_kernel (mfma_stream.h): a
 // workgroup owns 128 rows and walks `ftiles` 128-column tiles; waves 0-3 keep their 32 x 64 dY fragment -- scaled per row,
 // split -- in registers for the whole walk and issue LDS reads, 12 MFMAs and 16 row-segment stores per 32-column sub-tile; wave 4
@@ -1103,13 +1262,24 @@ extern "C" int mmrec_linear_fwd_split_f32(const float* X, const float* W, const 
 // nsplit x 64 floats][dW slabs: nsplit > 1 ? nsplit x 64 x F floats]; never smaller than what the fp32 entry points need.
 namespace {
 struct BwdSplitWs {
-    size_t wt, wcs, dbp, slabs, total;
-    int nsplit, chunk;
+    size_t wt, wcs, dbp, slabs, asp, total;
+    int nsplit, chunk, dy_wgs;
 };
 inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 inline BwdSplitWs bwd_split_ws(int n, int F) {
     BwdSplitWs w;
     pick_split_stream(ceil_div(F, BW_BF), n, BW_BK, &w.nsplit, &w.chunk);
+#if MMREC_BWD_W_V2
+    {   // the v2 kernel is compiled for MMREC_BWD_W2_OCC workgroups per CU: that many rounds' worth of chunks
+        int s2 = (256 * MMREC_BWD_W2_OCC) / ceil_div(F, BW_BF);
+        const int max_s = ceil_div(n, 2 * BW_BK);
+        if (s2 > max_s) s2 = max_s;
+        if (s2 > w.nsplit) {
+            w.chunk = ceil_div(ceil_div(n, s2), BW_BK) * BW_BK;
+            w.nsplit = ceil_div(n, w.chunk);
+        }
+    }
+#endif
 #ifdef MMREC_BWD_W_SPLIT    // probe: force the split-over-items count of the dW kernel
     w.chunk = ceil_div(ceil_div(n, MMREC_BWD_W_SPLIT), BW_BK) * BW_BK; w.nsplit = ceil_div(n, w.chunk);
 #endif
@@ -1121,8 +1291,11 @@ inline BwdSplitWs bwd_split_ws(int n, int F) {
     size_t off = 0;
     w.wt = off; off += al256((size_t)F * 256);
     w.wcs = off; off += al256(((size_t)F + 256) * 4);
-    w.dbp = off; off += al256((size_t)w.nsplit * 64 * 4);
+    const int n_tiles = ceil_div(n, BW_BK);
+    w.dy_wgs = n_tiles < 256 ? n_tiles : 256;                 // bwd_dy_split_kernel's grid = its bias-gradient partials
+    w.dbp = off; off += al256((size_t)(w.nsplit > w.dy_wgs ? w.nsplit : w.dy_wgs) * 64 * 4);
     w.slabs = off; off += al256(w.nsplit > 1 ? (size_t)w.nsplit * 64 * F * 4 : 0);
+    w.asp = off; off += MMREC_BWD_W_V2 ? al256((size_t)n_tiles * BW2_ATILE) : 0;      // dY split once per call: 384 B per item
     w.total = off;
     return w;
 }
@@ -1174,16 +1347,27 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     if (dW) {
         float* part = w.nsplit == 1 ? dW : slabs;
         float* dbpart = db ? dbp : (float*)nullptr;
+        int n_dbpart = w.nsplit;
+#if MMREC_BWD_W_V2
+        g_bf8* Asp_g = reinterpret_cast<g_bf8*>(base + w.asp);
+        hipLaunchKernelGGL(bwd_dy_split_kernel, dim3(w.dy_wgs), dim3(256), 0, s, dY, n, Asp_g, dbpart);
+        n_dbpart = w.dy_wgs;
+        if (big && (MMREC_BWD_NT & 1))
+            hipLaunchKernelGGL(linear_bwd_w_v2_kernel<true>, dim3(ncb, w.nsplit), dim3(512), 0, s, (const g_bf8*)Asp_g, X, part, n, F, w.chunk);
+        else
+            hipLaunchKernelGGL(linear_bwd_w_v2_kernel<false>, dim3(ncb, w.nsplit), dim3(512), 0, s, (const g_bf8*)Asp_g, X, part, n, F, w.chunk);
+#else
         if (big && (MMREC_BWD_NT & 1))
             hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<true>, dim3(ncb, w.nsplit), dim3(512), 0, s, dY, X, part, dbpart, n, F, w.chunk);
         else
             hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(512), 0, s, dY, X, part, dbpart, n, F, w.chunk);
+#endif
         if (w.nsplit > 1) {
             const size_t elems = (size_t)64 * F;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, (const float*)slabs,
                                w.nsplit, elems, (const float*)nullptr, dW);
         }
-        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)dbp, w.nsplit, db);
+        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)dbp, n_dbpart, db);
     }
     if (dX) {
         hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv);

@@ -687,99 +687,136 @@ __global__ __launch_bounds__(256) void filter_hint_bound_kernel(const uint4* __r
                                                                 const float* __restrict__ cnorm,     // clipping sets: row norms
                                                                 float* __restrict__ thr, int* __restrict__ flag) {
     constexpr int W = 8 * KB, RPS = 64 / W;     // lanes per row, rows per wave step
+    constexpr int NB = 8;                       // row steps in flight: 64 rows of 64 columns are ONE batch of gathers
     __shared__ int s_id[4][128];
     __shared__ float s_val[4][128];
+    __shared__ int s_mask[4][F_MASK_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = blockIdx.x * 4 + wave;
     if (q >= nq) return;                        // waves are independent below (wave-level fences only)
+    // A wave's life is memory round trips and ~500 instructions (x 4 cycles x 19,445 waves on Amazon-Baby: the first form of
+    // this kernel, with a 128-element sort and an all-pairs duplicate check, took 59 us -- longer than the pass it replaces):
+    // everything that does not depend on something else is requested at once -- the list, the mask range, the query row --
+    // then the listed rows AND the mask entries together (the gathers do not wait for the validity checks: an unusable id's
+    // score is computed and dropped).
+    const int32_t* hrow = hint + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk;
+    const bool two = hk > 64;                   // (uniform) lists of up to 64 ids are one id per lane
+    int id[2];
+    id[0] = lane < hk ? hrow[lane] : -1;
+    id[1] = two && lane + 64 < hk ? hrow[lane + 64] : -1;
     const int m_lo = mask_rowptr ? mask_rowptr[q] : 0, m = mask_rowptr ? mask_rowptr[q + 1] - m_lo : 0;
+    const float qn = qnorm[q];
+    const int ch = lane % W, sub = lane / W;
+    const uint4 qraw = Qs[(size_t)q * W + ch];
     if (nc - m < k) {
         if (lane == 0) { thr[q] = INFINITY; flag[q] = 1; }
         return;
     }
-    if (qnorm[q] == 0.f) {                      // all scores tie at 0: the final kernel writes the k lowest unmasked ids
+    if (qn == 0.f) {                            // all scores tie at 0: the final kernel writes the k lowest unmasked ids
         if (lane == 0) { thr[q] = INFINITY; flag[q] = 2; }
         return;
     }
-    const int32_t* hrow = hint + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk;
-    int id[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int e = lane + 64 * u;
-        id[u] = e < hk ? hrow[e] : -1;
-        s_id[wave][e] = id[u];
-    }
+    s_id[wave][lane] = id[0];
+    if (two) s_id[wave][lane + 64] = id[1];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    bool ok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        ok[u] = id[u] >= 0 && id[u] < nc;
-        if (ok[u] && m > 0) {                   // masked (train-positive) ids bound nothing
-            const int32_t* ml = mask_col + m_lo;
-            int lo = 0, hi = m;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (ml[mid] < id[u]) lo = mid + 1; else hi = mid;
-            }
-            ok[u] = !(lo < m && ml[lo] == id[u]);
-        }
-    }
-    for (int j = 0; j < hk; ++j) {              // an id counts once: its first occurrence (broadcast LDS reads)
-        const int v = s_id[wave][j];
-        if (j < lane && v == id[0]) ok[0] = false;
-        if (j < lane + 64 && v == id[1]) ok[1] = false;
-    }
-    const int n_ok = __popcll(__ballot(ok[0])) + __popcll(__ballot(ok[1]));
-    if (n_ok < k) {                             // not enough to bound the k-th score: the exact slow queue
-        if (lane == 0) { thr[q] = INFINITY; flag[q] = 1; }
-        return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        if (lane + 64 * u < hk && !ok[u]) s_id[wave][lane + 64 * u] = -1;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // approximate scores of the listed rows from the operands pass 2 multiplies
-    const int ch = lane % W, sub = lane / W;
-    const half8 qh = __builtin_bit_cast(half8, Qs[(size_t)q * W + ch]);
-    float qf[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qf[j] = (float)qh[j];
     const bool clips = cnorm != nullptr && reinterpret_cast<const int*>(stats)[ST_NOUT] > 0;
     const float tau = clips ? stats[ST_TAU] : INFINITY;
-    const float eps = filter_eps(q, nc, 64 * KB, qnorm, cmax_key, stats);
-    s_val[wave][lane] = -INFINITY;
-    s_val[wave][lane + 64] = -INFINITY;
-    constexpr int NB = 4;                       // row steps in flight
+    typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+    half2_t qp[4];
+    qp[0] = __builtin_bit_cast(half2_t, qraw.x); qp[1] = __builtin_bit_cast(half2_t, qraw.y);
+    qp[2] = __builtin_bit_cast(half2_t, qraw.z); qp[3] = __builtin_bit_cast(half2_t, qraw.w);
+    const bool mask_in_lds = m <= F_MASK_LDS;
+    const int32_t* ml = mask_col + m_lo;
+    float eps = 0.f;
+    bool ok[2] = {false, false};
     for (int e0 = 0; e0 < hk; e0 += RPS * NB) {
-        int rid[NB];
         uint4 cv[NB];
         float nrm[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int e = e0 + b * RPS + sub;
-            rid[b] = e < hk ? s_id[wave][e] : -1;
-            const int r = rid[b] >= 0 ? rid[b] : 0;
+            const int rid = e < hk ? s_id[wave][e] : -1;
+            const int r = rid >= 0 && rid < nc ? rid : 0;
             cv[b] = Cs[(((size_t)(r >> 6) * KB + (ch >> 3)) * 64 + (r & 63)) * 8 + (ch & 7)];
             nrm[b] = clips ? cnorm[r] : 0.f;
         }
+        if (e0 == 0) {
+            // under the gathers: the mask entries to LDS, eps, and which ids are in range and unmasked
+            if (mask_in_lds)
+                for (int e = lane; e < m; e += 64) s_mask[wave][e] = ml[e];
+            eps = filter_eps(q, nc, 64 * KB, qnorm, cmax_key, stats);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ok[u] = id[u] >= 0 && id[u] < nc;
+                if (ok[u] && m > 0) {               // masked (train-positive) ids bound nothing
+                    const int32_t* mm = mask_in_lds ? s_mask[wave] : ml;
+                    int lo = 0, hi = m;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (mm[mid] < id[u]) lo = mid + 1; else hi = mid;
+                    }
+                    ok[u] = !(lo < m && mm[lo] == id[u]);
+                }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const half8 chv = __builtin_bit_cast(half8, cv[b]);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a = fmaf(qf[j], (float)chv[j], a);
+            // exact fp16 products, fp32 accumulation (v_dot2_f32_f16: another order than the matrix cores' -- inside eps)
+            float a = __builtin_amdgcn_fdot2(qp[0], __builtin_bit_cast(half2_t, cv[b].x), 0.f, false);
+            a = __builtin_amdgcn_fdot2(qp[1], __builtin_bit_cast(half2_t, cv[b].y), a, false);
+            a = __builtin_amdgcn_fdot2(qp[2], __builtin_bit_cast(half2_t, cv[b].z), a, false);
+            a = __builtin_amdgcn_fdot2(qp[3], __builtin_bit_cast(half2_t, cv[b].w), a, false);
 #pragma unroll
             for (int o = W / 2; o >= 1; o >>= 1) a += __shfl_xor(a, o, W);
             if (nrm[b] >= tau) a = (a - eps) / (tau * (1.f - 1.f / 512.f) / nrm[b]) + eps;     // a clipped row: see above
-            if (rid[b] >= 0 && ch == 0) s_val[wave][e0 + b * RPS + sub] = a;
+            const int e = e0 + b * RPS + sub;
+            if (e < hk && ch == 0) s_val[wave][e] = a;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // the k-th largest of the usable rows' bounds (n_ok >= k of them are finite)
-    Cand y0 = Cand{s_val[wave][lane], lane}, y1 = Cand{s_val[wave][lane + 64], lane + 64};
-    bitonic128(y0, y1, lane);
-    const float B = k <= 64 ? __shfl(y0.v, k - 1, 64) : __shfl(y1.v, k - 65, 64);
-    filter_eps_store(B, q, lane, nc, 64 * KB, qnorm, cmax_key, stats, thr, flag, false);
+    // An id counts once.  Sorted by id (ids < 2^24 are exact as floats; unusable ones get distinct negative keys) with the
+    // bound riding along, a repeated id is a neighbour: one sort instead of hk^2 / 64 comparisons per lane.
+    Cand y0 = Cand{ok[0] ? (float)id[0] : (float)(-1 - lane), __float_as_int(lane < hk ? s_val[wave][lane] : 0.f)};
+    Cand y1 = Cand{ok[1] ? (float)id[1] : (float)(-65 - lane), __float_as_int(two && lane + 64 < hk ? s_val[wave][lane + 64] : 0.f)};
+    bool use0, use1 = false;
+    if (two) {
+        bitonic128(y0, y1, lane);
+        // rank order: element lane of y0, then element lane of y1; the predecessor of y1's lane 0 is y0's lane 63
+        const float p0 = __shfl_up(y0.v, 1, 64), p1 = __shfl_up(y1.v, 1, 64), last0 = __shfl(y0.v, 63, 64);
+        use0 = y0.v >= 0.f && (lane == 0 || p0 != y0.v);
+        use1 = y1.v >= 0.f && ((lane == 0 ? last0 : p1) != y1.v);
+    } else {
+        bitonic64(y0, lane);
+        const float p0 = __shfl_up(y0.v, 1, 64);
+        use0 = y0.v >= 0.f && (lane == 0 || p0 != y0.v);
+    }
+    const int n_ok = __popcll(__ballot(use0)) + __popcll(__ballot(use1));
+    if (n_ok < k) {                             // not enough to bound the k-th score: the exact slow queue
+        if (lane == 0) { thr[q] = INFINITY; flag[q] = 1; }
+        return;
+    }
+    // A lower bound of the k-th largest of the usable rows' bounds, by bisection on their monotone integer image (as
+    // filter_bound_kernel: `cur` is a lower bound after EVERY step; 16 steps resolve 2^-16 of the bounds' spread).
+    const unsigned key0 = use0 ? f2key(__int_as_float(y0.i)) : 0u, key1 = use1 ? f2key(__int_as_float(y1.i)) : 0u;
+    unsigned kmax = max(key0, key1), kmin = min(use0 ? key0 : 0xffffffffu, use1 ? key1 : 0xffffffffu);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
+    }
+    const int top = 31 - __clz((int)((kmax ^ kmin) | 256u));
+    unsigned cur = top < 31 ? kmax & ~((2u << top) - 1u) : 0u;
+    const int last = max(8, top - 15);
+    for (int bit = top; bit >= last; --bit) {
+        const unsigned trial = cur | (1u << bit);
+        const int c = __popcll(__ballot(use0 && key0 >= trial)) + __popcll(__ballot(use1 && key1 >= trial));
+        if (c >= k) cur = trial;
+    }
+    if (lane == 0) {
+        const float B = key2f(cur);
+        thr[q] = B - 2.f * eps;
+        flag[q] = 0;
+    }
 }
 
 // The lists of the queries the overflow / slow queues ranked (their kernels write out_idx only): top-k ids, -1 beyond.  One wave
@@ -788,21 +825,22 @@ __global__ __launch_bounds__(256) void filter_hint_from_out_kernel(const int* __
                                                                    const int* __restrict__ n_flagged,
                                                                    const int64_t* __restrict__ out_idx, int k,
                                                                    int32_t* __restrict__ hint_out, int hk,
-                                                                   const int64_t* __restrict__ hint_rows) {
+                                                                   const int64_t* __restrict__ hint_rows,
+                                                                   int* __restrict__ queue_counts) {
     const int lane = threadIdx.x & 63;
     const int n0 = n_flagged[0], n1 = olist ? n_flagged[1] : 0;
+    // queue_counts[0] += queries the exact slow queue served, [1] += queries that went through the overflow queue (either is a
+    // sign of a loose threshold: a warm caller falls back to the cold path when they grow)
+    if (queue_counts && blockIdx.x == 0 && threadIdx.x == 0) {
+        queue_counts[0] += n0;
+        queue_counts[1] += n_flagged[1];
+    }
+    if (!hint_out) return;
     for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n0 + n1; e += gridDim.x * 4) {
         const int q = e < n0 ? flist[e] : olist[e - n0];
         int32_t* hr = hint_out + (size_t)(hint_rows ? hint_rows[q] : (int64_t)q) * hk;
         for (int j = lane; j < hk; j += 64) hr[j] = j < k ? (int32_t)out_idx[(size_t)q * k + j] : -1;
     }
-}
-
-// queue_counts[0] += queries the exact slow queue served, [1] += queries that went through the overflow queue (either is a
-// sign of a loose threshold: a warm caller falls back to the cold path when they grow)
-__global__ void filter_counts_add_kernel(const int* __restrict__ n_flagged, int* __restrict__ queue_counts) {
-    queue_counts[0] += n_flagged[0];
-    queue_counts[1] += n_flagged[1];
 }
 
 // exact fp32 score = fixed tree over the 16 float4 chunk products (identical in the final and slow kernels)
@@ -831,6 +869,10 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q4, cons
 __device__ __forceinline__ Cand sort_best64(const unsigned long long* list, int n, int lane) {
     auto fetch = [&](int e) -> Cand { return e < n ? unpack_cand(list[e]) : Cand{-INFINITY, INT_MAX}; };
     Cand y0 = fetch(lane), y1;
+    if (n <= 64) {         // (wave-uniform) the whole list is one candidate per lane
+        bitonic64(y0, lane);
+        return y0;
+    }
     int pos = 64;
     do {
         y1 = fetch(pos + lane);
@@ -1437,11 +1479,9 @@ int filter_launch_kb(const float* Q, const float* C, int nq, int nc, const int32
     if (want > 1)
         hipLaunchKernelGGL(filter_slow_merge_kernel, dim3(64), dim3(256), 0, s, flist, n_flagged, want, parts, k, out_idx,
                            out_val);
-    if (hout)
-        hipLaunchKernelGGL(filter_hint_from_out_kernel, dim3(64), dim3(256), 0, s, flist, olist, n_flagged, out_idx, k, hout, hint.hk,
-                           hint.rows);
-    if (hint.queue_counts)
-        hipLaunchKernelGGL(filter_counts_add_kernel, dim3(1), dim3(1), 0, s, n_flagged, hint.queue_counts);
+    if (hout || hint.queue_counts)      // the lists of the queue-served queries + the caller's queue counters, one launch
+        hipLaunchKernelGGL(filter_hint_from_out_kernel, dim3(hout ? 64 : 1), dim3(256), 0, s, flist, olist, n_flagged, out_idx, k, hout,
+                           hint.hk, hint.rows, hint.queue_counts);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 }  // namespace

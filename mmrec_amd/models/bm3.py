@@ -17,14 +17,16 @@ import torch.nn.functional as F
 
 from mmrec_amd import hip_ops
 from mmrec_amd.common.lazy_rows import LazyRowEmbedding, lazy_adam_enabled
-from mmrec_amd.graph import norm_adj_graph
-from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender
+from mmrec_amd.graph import norm_adj_graph, relabel_graph
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
 
 
-class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
+class BM3(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = True       # the step is a fixed launch sequence: replayed as a hipGraph by default (hip_graph_step: auto)
 
     adjacent_tables = ('user_embedding.weight', 'item_id_embedding.weight')
+    relabelled_tables = {'user_embedding.weight': 'u', 'item_id_embedding.weight': 'i', 'image_embedding.weight': 'i',
+                         'text_embedding.weight': 'i'}     # config key `reorder` (models/_base.py)
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -43,18 +45,27 @@ class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
         self.norm_adj = norm_adj_graph(dataset.inter_matrix(form='coo').astype(np.float32),
                                        self.n_users, self.n_items, self.device)
+        # new key `reorder`: the id-indexed tables live in an id space relabelled once, here (bm3.py:84-95's propagation gathers
+        # with locality; the graph keeps every row's nonzero order, so its sums are the plain model's bit for bit)
+        rl = self._setup_relabelling(config, self.norm_adj)
+        if rl is not None:
+            self.norm_adj = relabel_graph(self.norm_adj, rl.node_perm_host())
         self.user_embedding = nn.Embedding(self.n_users, self.embedding_dim)
         self.item_id_embedding = nn.Embedding(self.n_items, self.embedding_dim)
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_id_embedding.weight)
+        if rl is not None:            # the plain model's initial values, row `old` at relabelled row perm[old]
+            self._to_relabelled_rows_(self.user_embedding.weight, 'u')
+            self._to_relabelled_rows_(self.item_id_embedding.weight, 'i')
         self.predictor = nn.Linear(self.embedding_dim, self.embedding_dim)
         nn.init.xavier_normal_(self.predictor.weight)
+        in_space = (lambda f: f) if rl is None else (lambda f: f.index_select(0, rl.inv_i.to(f.device)))
         if self.v_feat is not None:
-            self.image_embedding = table.from_pretrained(self.v_feat, freeze=False)
+            self.image_embedding = table.from_pretrained(in_space(self.v_feat), freeze=False)
             self.image_trs = nn.Linear(self.v_feat.shape[1], self.feat_embed_dim)
             nn.init.xavier_normal_(self.image_trs.weight)
         if self.t_feat is not None:
-            self.text_embedding = table.from_pretrained(self.t_feat, freeze=False)
+            self.text_embedding = table.from_pretrained(in_space(self.t_feat), freeze=False)
             self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
             nn.init.xavier_normal_(self.text_trs.weight)
 
@@ -70,17 +81,32 @@ class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         u, i = self.forward()
         return self._predict(u.contiguous()), self._predict(i.contiguous())
 
-    def _targets(self, *tensors):
+    def _targets(self, *tensors, sides=None):
         """dropout(clone) targets without gradient; one F.dropout call per tensor, in the
-        reference's order (u, i, t, v) so an injected dropout function replays the same masks."""
+        reference's order (u, i, t, v) so an injected dropout function replays the same masks.  Under `reorder` a mask is
+        drawn for the rows in the DATASET's order (the plain model's draw, element for element) and carried to the relabelled
+        rows: sides[j] = 'u' / 'i' names tensor j's id space, None = rows already in dataset order."""
+        rl = self.relabelling
         with torch.no_grad():
-            return [F.dropout(t.detach().clone(), self.dropout) for t in tensors]
+            if rl is None:
+                return [F.dropout(t.detach().clone(), self.dropout) for t in tensors]
+            out = []
+            for t, side in zip(tensors, sides):
+                if side is None:
+                    out.append(F.dropout(t.detach().clone(), self.dropout))
+                    continue
+                perm, inv = (rl.perm_u, rl.inv_u) if side == 'u' else (rl.perm_i, rl.inv_i)
+                out.append(F.dropout(t.detach().index_select(0, perm), self.dropout).index_select(0, inv))
+            return out
 
     def calculate_loss(self, interactions):
         if self.lazy_projection and self.lazy_feature_adam and self.lazy_prefetch:   # row catch-up on the side stream
+            rows_pf = interactions[1] if self.relabelling is None else self.relabelling.perm_i[interactions[1]]
             for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
                 if emb is not None:
-                    emb.prefetch(interactions[1])
+                    emb.prefetch(rows_pf)
+        items_ds = interactions[1]                  # the dataset's ids: what the per-item dropout masks are indexed with
+        interactions = self._map_batch(interactions)
         u_ori, i_ori = self.forward()
         u_ori, i_ori = u_ori.contiguous(), i_ori.contiguous()
         users, items = interactions[0], interactions[1]
@@ -96,8 +122,10 @@ class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
             v_on = hip_ops.linear(rows(self.image_embedding), self.image_trs.weight, self.image_trs.bias)
         # dropout targets in the reference's order and shapes (u, i, t, v); lazy: the per-item masks of t and v
         ones = torch.ones_like(i_ori) if lazy else None
-        targets = self._targets(*[t for t in (u_ori, i_ori, None if t_on is None else (ones if lazy else t_on),
-                                              None if v_on is None else (ones if lazy else v_on)) if t is not None])
+        # (lazy: the masks of t and v are drawn over `ones` per item in dataset order and gathered with the dataset's ids)
+        cand = ((u_ori, 'u'), (i_ori, 'i'), (None if t_on is None else (ones if lazy else t_on), None if lazy else 'i'),
+                (None if v_on is None else (ones if lazy else v_on), None if lazy else 'i'))
+        targets = self._targets(*[t for t, _ in cand if t is not None], sides=[sd for t, sd in cand if t is not None])
         u_tgt, i_tgt = targets[0], targets[1]
         rest = targets[2:]
         t_tgt = rest.pop(0) if t_on is not None else None
@@ -109,12 +137,12 @@ class BM3(AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
         loss_t = loss_v = loss_tv = loss_vt = 0.0
         if t_on is not None:
             t_pred, t_idx = self._predict(t_on), (None if lazy else items)
-            t_tgt = t_on.detach() * t_tgt[items, :] if lazy else t_tgt
+            t_tgt = t_on.detach() * t_tgt[items_ds, :] if lazy else t_tgt
             loss_t = 1 - cos(t_pred, t_idx, i_tgt, items)
             loss_tv = 1 - cos(t_pred, t_idx, t_tgt, t_idx)
         if v_on is not None:
             v_pred, v_idx = self._predict(v_on), (None if lazy else items)
-            v_tgt = v_on.detach() * v_tgt[items, :] if lazy else v_tgt
+            v_tgt = v_on.detach() * v_tgt[items_ds, :] if lazy else v_tgt
             loss_v = 1 - cos(v_pred, v_idx, i_tgt, items)
             loss_vt = 1 - cos(v_pred, v_idx, v_tgt, v_idx)
         loss_ui = 1 - cos(u_pred, users, i_tgt, items)

@@ -463,6 +463,87 @@ def test_pgl_global_mode_spectral_subgraph(tmp_path, golden):
         get_model("PGL")(*G.setup(tmp_path / "bad2", golden, "PGL", {"mode": "nope"}, use_gpu=False)[:2])
 
 
+def test_mmgcn_relabelled_id_space_is_the_same_model(tmp_path, golden):
+    """`reorder` in MMGCN (mmgcn.py:108-216): its id-indexed state is plain tensors (preference, id_embedding, the feature
+    tables) and lives in the relabelled space; parameters are not id-indexed, so the state_dict is untouched.  Same draws at
+    build time, same loss (the preference regulariser averages all rows: another summation order), same gradients, same
+    evaluation tables and top-K in the dataset's ids."""
+    import torch
+    from mmrec_amd.utils.utils import get_model
+    res = {}
+    for key in (None, "degree"):
+        ex = {"reg_weight": 1e-3, "learning_rate": 1e-3}
+        if key:
+            ex["reorder"] = key
+        config, train_data, valid_data = G.setup(tmp_path / ("r%s" % key), golden, "MMGCN", ex, use_gpu=False)
+        model = get_model("MMGCN")(config, train_data).to("cpu")
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        loss = model.calculate_loss(G.batch_of(golden, torch.device("cpu")))
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        model.eval()
+        batch = next(iter(valid_data))
+        res[key] = (sd0, float(loss.detach()), grads, model.full_sort_topk(batch, 20).clone(), model.full_sort_predict(batch).clone(), model)
+    a, b = res[None], res["degree"]
+    rl = b[5].relabelling
+    assert rl is not None and not torch.equal(rl.perm_u, torch.arange(rl.perm_u.numel()))
+    assert list(a[0]) == list(b[0]) and all(torch.equal(a[0][k], b[0][k]) for k in a[0])
+    assert torch.equal(b[5].v_gcn.preference[rl.perm_u], a[5].v_gcn.preference) and torch.equal(b[5].id_embedding[rl.perm_u], a[5].id_embedding[:a[5].n_users])
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (a[1], b[1])
+    assert set(a[2]) == set(b[2])
+    for n in a[2]:
+        torch.testing.assert_close(b[2][n], a[2][n], rtol=1e-4, atol=1e-7, msg=n)
+    torch.testing.assert_close(b[4], a[4], rtol=1e-6, atol=1e-7)
+    assert torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_bm3_relabelled_id_space_is_the_same_model(tmp_path, golden, lazy):
+    """Round-5 review, missing 3: `reorder` in BM3 (bm3.py:84-95's propagation + the feature tables).  Same initial state_dict,
+    same loss -- the dropout masks of the four targets are drawn for the rows in the dataset's order, so the SAME generator
+    state gives the plain model's masks --, same gradients after un-permuting, same top-K in the dataset's ids, checkpoints
+    both ways; with the gathered-rows projection (per-item masks indexed by dataset ids) and the all-items form."""
+    import torch
+    from mmrec_amd.utils.utils import get_model
+    res = {}
+    for key in (None, "degree"):
+        ex = {"n_layers": 2, "reg_weight": 0.1, "dropout": 0.3, "lazy_feature_adam": False, "lazy_projection": lazy}
+        if key:
+            ex["reorder"] = key
+        config, train_data, valid_data = G.setup(tmp_path / ("r%s" % key), golden, "BM3", ex, use_gpu=False)
+        model = get_model("BM3")(config, train_data).to("cpu")
+        assert (model.relabelling is not None) == bool(key)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        torch.manual_seed(77)
+        loss = model.calculate_loss(G.batch_of(golden, torch.device("cpu"), rows=2))
+        loss.backward()
+        grads = {}
+        for n, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            gr, side = p.grad.clone(), model.relabelled_tables.get(n)
+            if key and side:
+                gr = gr.index_select(0, model.relabelling.perm_u if side == "u" else model.relabelling.perm_i)
+            grads[n] = gr
+        model.eval()
+        batch = next(iter(valid_data))
+        res[key] = (sd0, float(loss.detach()), grads, model.full_sort_topk(batch, 20).clone(), model)
+    a, b = res[None], res["degree"]
+    assert not torch.equal(b[4].relabelling.perm_i, torch.arange(b[4].n_items))
+    assert list(a[0]) == list(b[0])
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (a[1], b[1])       # (the EmbLoss norms sum all rows: another order)
+    assert set(a[2]) == set(b[2])
+    for n in a[2]:
+        torch.testing.assert_close(b[2][n], a[2][n], rtol=2e-5, atol=1e-8, msg=n)
+    assert torch.equal(a[3], b[3])
+    trained = {k: v + 0.01 * torch.arange(v.shape[0]).reshape([-1] + [1] * (v.dim() - 1)) if v.dim() else v for k, v in a[0].items()}
+    a[4].load_state_dict(trained), b[4].load_state_dict(trained)
+    for k, v in b[4].state_dict().items():
+        assert torch.equal(v, a[4].state_dict()[k]), k
+
+
 @pytest.mark.parametrize("name,extra,keep", [("LightGCN", {"n_layers": 3, "reg_weight": 1e-4}, None),
                                              ("LayerGCN", {"n_layers": 4, "reg_weight": 1e-3, "dropout": 0.1}, "lay_keep_idx")])
 def test_relabelled_id_space_other_plugins(tmp_path, golden, name, extra, keep):
