@@ -661,9 +661,9 @@ __device__ __forceinline__ void pow2_scale(float mx, int target, float& sc, floa
 // W [64][F] -> Wt_sp: row f = 256 B = 16 chunks of 16 B: chunks 0..7 the fp16 hi halves of cs_f w[8c .. 8c + 7][f], chunks 8..15
 // the lo' halves; chunk c is stored at position c ^ (f & 15) (the LDS-DMA copies a 128-row tile linearly; the swizzle makes the
 // 16-B fragment reads of 32 consecutive rows conflict free).  wcs_inv[f] = 1 / cs_f.
-__global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wt_sp,
-                                                           float* __restrict__ wcs_inv) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void bwd_wt_split_body(int block, const float* __restrict__ W, int F, float* __restrict__ Wt_sp,
+                                                  float* __restrict__ wcs_inv) {
+    const int f = block * 256 + threadIdx.x;
     if (f >= F) return;
     float w[64], mx = 0.f;
 #pragma unroll
@@ -685,6 +685,10 @@ __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restri
         *reinterpret_cast<g_half8*>(row + ((c ^ (f & 15)) << 2)) = hi;
         *reinterpret_cast<g_half8*>(row + (((8 + c) ^ (f & 15)) << 2)) = lo;
     }
+}
+__global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restrict__ W, int F, float* __restrict__ Wt_sp,
+                                                           float* __restrict__ wcs_inv) {
+    bwd_wt_split_body(blockIdx.x, W, F, Wt_sp, wcs_inv);
 }
 
 // dW partial[o][f] over an item chunk on v_mfma_f32_32x32x16_bf16 with THREE-WAY split operands: every fp32 number is
@@ -882,14 +886,14 @@ __global__ __launch_bounds__(512) void linear_bwd_w_bf16x3_kernel(const float* _
 constexpr int BW2_ATILE = 12 * 64 * 16;      // bytes of a tile's split dY fragments
 
 // grid: min(#tiles, 256) workgroups of 4 waves; workgroup g takes tiles g, g + G, ...; wave w = fragment (kstep = w >> 1, otile = w & 1).
-__global__ __launch_bounds__(256) void bwd_dy_split_kernel(const float* __restrict__ dY, int n, g_bf8* __restrict__ Asp_g,
-                                                          float* __restrict__ dbpart) {
+__device__ __forceinline__ void bwd_dy_split_body(int block, int n_blocks, const float* __restrict__ dY, int n,
+                                                  g_bf8* __restrict__ Asp_g, float* __restrict__ dbpart) {
     __shared__ float s_db[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int n_tiles = (n + BW_BK - 1) / BW_BK;
     float dbacc = 0.f;
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    for (int t = block; t < n_tiles; t += n_blocks) {
         const int item0 = t * BW_BK + 16 * (wave >> 1) + 8 * h;
         float x[8];
 #pragma unroll
@@ -908,9 +912,57 @@ __global__ __launch_bounds__(256) void bwd_dy_split_kernel(const float* __restri
         __syncthreads();
         if (threadIdx.x < 64) {
             const int ot = threadIdx.x >> 5, c = threadIdx.x & 31;
-            dbpart[blockIdx.x * 64 + threadIdx.x] = (s_db[ot][c] + s_db[ot][32 + c]) + (s_db[2 + ot][c] + s_db[2 + ot][32 + c]);
+            dbpart[block * 64 + threadIdx.x] = (s_db[ot][c] + s_db[ot][32 + c]) + (s_db[2 + ot][c] + s_db[2 + ot][32 + c]);
         }
     }
+}
+__global__ __launch_bounds__(256) void bwd_dy_split_kernel(const float* __restrict__ dY, int n, g_bf8* __restrict__ Asp_g,
+                                                          float* __restrict__ dbpart) {
+    bwd_dy_split_body(blockIdx.x, gridDim.x, dY, n, Asp_g, dbpart);
+}
+// Both operand preparations of a backward call that wants dW AND dX in ONE launch (as launches of their own they take ~5 us
+// each at Amazon-Baby size -- a sixth of the call was spent in six such kernels): workgroups [0, dy_wgs) split dY, the rest W^T.
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ dY, int n, g_bf8* __restrict__ Asp_g,
+                                                      float* __restrict__ dbpart, int dy_wgs, const float* __restrict__ W, int F,
+                                                      float* __restrict__ Wt_sp, float* __restrict__ wcs_inv) {
+    if ((int)blockIdx.x < dy_wgs) bwd_dy_split_body(blockIdx.x, dy_wgs, dY, n, Asp_g, dbpart);
+    else bwd_wt_split_body(blockIdx.x - dy_wgs, W, F, Wt_sp, wcs_inv);
+}
+// dW = sum of the item chunks' slabs (slab order) and, in the LAST workgroup, db = sum of the bias-gradient partials (four
+// slices of the partials in parallel, combined in slice order): one launch instead of slab_reduce_kernel + db_reduce_kernel.
+__global__ __launch_bounds__(256) void bwd_w_finish_kernel(const float* __restrict__ part, int nslab, size_t slab_elems,
+                                                          float* __restrict__ dW, const float* __restrict__ dbpart, int n_dbpart,
+                                                          float* __restrict__ db) {
+    __shared__ float red[4][64];
+    if (blockIdx.x + 1 == gridDim.x) {
+        if (!db) return;
+        const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        float t = 0.f, t2 = 0.f;
+        int s = sl;
+        for (; s + 4 < n_dbpart; s += 8) {          // two independent chains: the loads travel together
+            t += dbpart[s * 64 + c];
+            t2 += dbpart[(s + 4) * 64 + c];
+        }
+        if (s < n_dbpart) t += dbpart[s * 64 + c];
+        t += t2;
+        red[sl][c] = t;
+        __syncthreads();
+        if (sl == 0) db[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        return;
+    }
+    if (nslab <= 1) return;            // (a single chunk wrote dW itself)
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= slab_elems) return;
+    float4 t0 = f4_zero(), t1 = f4_zero(), t2 = f4_zero(), t3 = f4_zero();
+    int s = 0;
+    for (; s + 3 < nslab; s += 4) {      // four independent chains, fixed combination order (as slab_reduce_kernel)
+        t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)(s + 0) * slab_elems)[i4]);
+        t1 = f4_add(t1, reinterpret_cast<const float4*>(part + (size_t)(s + 1) * slab_elems)[i4]);
+        t2 = f4_add(t2, reinterpret_cast<const float4*>(part + (size_t)(s + 2) * slab_elems)[i4]);
+        t3 = f4_add(t3, reinterpret_cast<const float4*>(part + (size_t)(s + 3) * slab_elems)[i4]);
+    }
+    for (; s < nslab; ++s) t0 = f4_add(t0, reinterpret_cast<const float4*>(part + (size_t)s * slab_elems)[i4]);
+    reinterpret_cast<float4*>(dW)[i4] = f4_add(f4_add(t0, t1), f4_add(t2, t3));
 }
 
 template <bool NT>
@@ -1269,17 +1321,8 @@ inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 inline BwdSplitWs bwd_split_ws(int n, int F) {
     BwdSplitWs w;
     pick_split_stream(ceil_div(F, BW_BF), n, BW_BK, &w.nsplit, &w.chunk);
-#if MMREC_BWD_W_V2
-    {   // the v2 kernel is compiled for MMREC_BWD_W2_OCC workgroups per CU: that many rounds' worth of chunks
-        int s2 = (256 * MMREC_BWD_W2_OCC) / ceil_div(F, BW_BF);
-        const int max_s = ceil_div(n, 2 * BW_BK);
-        if (s2 > max_s) s2 = max_s;
-        if (s2 > w.nsplit) {
-            w.chunk = ceil_div(ceil_div(n, s2), BW_BK) * BW_BK;
-            w.nsplit = ceil_div(n, w.chunk);
-        }
-    }
-#endif
+    // (the v2 kernel fits two workgroups per CU, but twice the chunks measured 3 % SLOWER forward + backward at 7,050 rows and the
+    // same at 18,357 -- twice the slabs to sum; a quarter of the chunks 10 % slower: profiles/r06_linear_bwd_w_v2_ab.log)
 #ifdef MMREC_BWD_W_SPLIT    // probe: force the split-over-items count of the dW kernel
     w.chunk = ceil_div(ceil_div(n, MMREC_BWD_W_SPLIT), BW_BK) * BW_BK; w.nsplit = ceil_div(n, w.chunk);
 #endif
@@ -1292,7 +1335,9 @@ inline BwdSplitWs bwd_split_ws(int n, int F) {
     w.wt = off; off += al256((size_t)F * 256);
     w.wcs = off; off += al256(((size_t)F + 256) * 4);
     const int n_tiles = ceil_div(n, BW_BK);
-    w.dy_wgs = n_tiles < 256 ? n_tiles : 256;                 // bwd_dy_split_kernel's grid = its bias-gradient partials
+    // bwd_dy_split_kernel's grid = its bias-gradient partials, which ONE workgroup sums afterwards (64: 16 loads per thread; with
+    // 256 partials that chain of loads made the finishing launch 16 us instead of 5)
+    w.dy_wgs = n_tiles < 64 ? n_tiles : 64;
     w.dbp = off; off += al256((size_t)(w.nsplit > w.dy_wgs ? w.nsplit : w.dy_wgs) * 64 * 4);
     w.slabs = off; off += al256(w.nsplit > 1 ? (size_t)w.nsplit * 64 * F * 4 : 0);
     w.asp = off; off += MMREC_BWD_W_V2 ? al256((size_t)n_tiles * BW2_ATILE) : 0;      // dY split once per call: 384 B per item
@@ -1337,6 +1382,7 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
     float* slabs = reinterpret_cast<float*>(base + w.slabs);
     const int ncb = F / BW_BF;
     const bool big = (size_t)n * F * sizeof(float) > ((size_t)192 << 20);      // X / dX larger than the Infinity Cache
+    bool wt_done = false;
 #ifdef MMREC_BWD_W_FP32      // probe: dW by the fp32-MFMA kernel inside the split entry (A/B against the bf16 x 3 kernel)
     if (dW) {
         const int rc = mmrec_linear_bwd_w_f32(dY, X, dW, db, n, F, out, workspace, stream);
@@ -1350,7 +1396,13 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
         int n_dbpart = w.nsplit;
 #if MMREC_BWD_W_V2
         g_bf8* Asp_g = reinterpret_cast<g_bf8*>(base + w.asp);
-        hipLaunchKernelGGL(bwd_dy_split_kernel, dim3(w.dy_wgs), dim3(256), 0, s, dY, n, Asp_g, dbpart);
+        if (dX) {       // dY and W^T are split in one launch
+            hipLaunchKernelGGL(bwd_prep_kernel, dim3(w.dy_wgs + ceil_div(F, 256)), dim3(256), 0, s, dY, n, Asp_g, dbpart, w.dy_wgs,
+                               W, F, Wt_sp, wcs_inv);
+            wt_done = true;
+        } else {
+            hipLaunchKernelGGL(bwd_dy_split_kernel, dim3(w.dy_wgs), dim3(256), 0, s, dY, n, Asp_g, dbpart);
+        }
         n_dbpart = w.dy_wgs;
         if (big && (MMREC_BWD_NT & 1))
             hipLaunchKernelGGL(linear_bwd_w_v2_kernel<true>, dim3(ncb, w.nsplit), dim3(512), 0, s, (const g_bf8*)Asp_g, X, part, n, F, w.chunk);
@@ -1362,15 +1414,14 @@ extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const
         else
             hipLaunchKernelGGL(linear_bwd_w_bf16x3_kernel<false>, dim3(ncb, w.nsplit), dim3(512), 0, s, dY, X, part, dbpart, n, F, w.chunk);
 #endif
-        if (w.nsplit > 1) {
+        if (w.nsplit > 1 || db) {      // slabs -> dW and partials -> db, one launch
             const size_t elems = (size_t)64 * F;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, (const float*)slabs,
-                               w.nsplit, elems, (const float*)nullptr, dW);
+            hipLaunchKernelGGL(bwd_w_finish_kernel, dim3((unsigned)((elems / 4 + 255) / 256) + 1), dim3(256), 0, s, (const float*)slabs,
+                               w.nsplit, elems, dW, (const float*)dbp, n_dbpart, db);
         }
-        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)dbp, n_dbpart, db);
     }
     if (dX) {
-        hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv);
+        if (!wt_done) hipLaunchKernelGGL(bwd_wt_split_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, s, W, F, Wt_sp, wcs_inv);
         const int rt = ceil_div(n, 128), nft = F / 128;
         int ftiles = 8;
         while (ftiles > 1 && (long)rt * ceil_div(nft, ftiles) < 192) ftiles >>= 1;

@@ -766,8 +766,10 @@ __global__ __launch_bounds__(256) void filter_hint_bound_kernel(const uint4* __r
             a = __builtin_amdgcn_fdot2(qp[1], __builtin_bit_cast(half2_t, cv[b].y), a, false);
             a = __builtin_amdgcn_fdot2(qp[2], __builtin_bit_cast(half2_t, cv[b].z), a, false);
             a = __builtin_amdgcn_fdot2(qp[3], __builtin_bit_cast(half2_t, cv[b].w), a, false);
-#pragma unroll
-            for (int o = W / 2; o >= 1; o >>= 1) a += __shfl_xor(a, o, W);
+            if (W == 16) a += lane_xor_f<8>(a);
+            a += lane_xor_f<4>(a);
+            a += lane_xor_f<2>(a);
+            a += lane_xor_f<1>(a);
             if (nrm[b] >= tau) a = (a - eps) / (tau * (1.f - 1.f / 512.f) / nrm[b]) + eps;     // a clipped row: see above
             const int e = e0 + b * RPS + sub;
             if (e < hk && ch == 0) s_val[wave][e] = a;

@@ -13,10 +13,10 @@ struct Cand {
 __device__ __forceinline__ bool cand_before(Cand a, Cand b) {  // a ranks ahead of b
     return a.v > b.v || (a.v == b.v && a.i < b.i);
 }
-__device__ __forceinline__ Cand cand_shfl_xor(Cand c, int m) {
+__device__ __forceinline__ Cand cand_shfl_xor(Cand c, int m) {      // (m: a power of two, a constant after unrolling)
     Cand o;
-    o.v = __shfl_xor(c.v, m, 64);
-    o.i = __shfl_xor(c.i, m, 64);
+    o.v = lane_xor_f(c.v, m);
+    o.i = lane_xor_i(c.i, m);
     return o;
 }
 

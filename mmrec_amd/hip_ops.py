@@ -964,6 +964,9 @@ def cosine_mean(X, ix, Y, iy):
 # ------------------------------------------------------------------------------------------------
 # P3  modal projection
 # ------------------------------------------------------------------------------------------------
+LINEAR_SPLIT_MIN_F = 1024      # narrower inputs take the fp32-MFMA forward
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, b):
@@ -977,7 +980,9 @@ class _Linear(torch.autograd.Function):
             b = _chk(b.contiguous(), torch.float32, "b", 1)
         Y = torch.empty(n, 64, dtype=torch.float32, device=X.device)
         ws = _ws(lib.mmrec_linear_workspace_bytes(n, F, 64), X.device)
-        fwd = lib.mmrec_linear_fwd_split_f32 if LINEAR_F16X3 else lib.mmrec_linear_fwd_f32
+        # narrow tables (the 384-wide text features) are launch bound, not stream bound: the fp32 kernel is ONE launch where the
+        # split form is three or four (W split, kernel, slab sum, guard fix-up): 19 us against 24 at 7,050 x 384
+        fwd = lib.mmrec_linear_fwd_split_f32 if (LINEAR_F16X3 and F >= LINEAR_SPLIT_MIN_F) else lib.mmrec_linear_fwd_f32
         _lib.check(fwd(_p(X), _p(W), _p(b), _p(Y), n, F, 64, _p(ws), _stream()), "linear_fwd")
         ctx.save_for_backward(X, W)
         ctx.has_b = b is not None

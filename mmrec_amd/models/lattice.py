@@ -17,7 +17,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mmrec_amd import hip_ops
-from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
+from mmrec_amd.graph import relabel_graph
+from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
 
 
 def _sym_norm_values(rows, cols, vals, n):
@@ -28,8 +29,10 @@ def _sym_norm_values(rows, cols, vals, n):
     return d[rows] * vals * d[cols]
 
 
-class LATTICE(FusedEvalMixin, GeneralRecommender):
+class LATTICE(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
     graph_capturable = False   # the first batch of an epoch builds the item graph, later ones do not
+    relabelled_tables = {'user_embedding.weight': 'u', 'item_id_embedding.weight': 'i', 'image_embedding.weight': 'i',
+                         'text_embedding.weight': 'i'}     # config key `reorder` (models/_base.py)
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -45,6 +48,14 @@ class LATTICE(FusedEvalMixin, GeneralRecommender):
 
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
         self.norm_adj = self._row_norm_graph()
+        # new key `reorder`: the u-i propagation (lattice.py:184-195) and every id-indexed table in an id space relabelled once,
+        # here.  The kNN graphs are still FOUND in the dataset's ids (ties between equal similarities go to the lower dataset
+        # id, the reference's cache files keep their meaning) and their (row, col) pairs renamed in order, so every row of
+        # every graph sums the plain model's terms in the plain model's order.
+        rl = self._setup_relabelling(config, self.norm_adj)
+        if rl is not None:
+            self.norm_adj = relabel_graph(self.norm_adj, rl.node_perm_host())
+        in_space = (lambda f: f) if rl is None else (lambda f: f.index_select(0, rl.inv_i.to(f.device)))
         self.item_adj = None      # (DynGraph, values) of the current item graph
 
         self.n_ui_layers = len(self.weight_size)
@@ -53,6 +64,9 @@ class LATTICE(FusedEvalMixin, GeneralRecommender):
         self.item_id_embedding = nn.Embedding(self.n_items, self.embedding_dim)
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_id_embedding.weight)
+        if rl is not None:            # the plain model's initial values, row `old` at relabelled row perm[old]
+            self._to_relabelled_rows_(self.user_embedding.weight, 'u')
+            self._to_relabelled_rows_(self.item_id_embedding.weight, 'i')
         if self.cf_model == 'ngcf':
             self.GC_Linear_list, self.Bi_Linear_list, self.dropout_list = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
             for i in range(self.n_ui_layers):
@@ -62,11 +76,11 @@ class LATTICE(FusedEvalMixin, GeneralRecommender):
 
         dataset_path = os.path.abspath(config['data_path'] + config['dataset'])
         if self.v_feat is not None:
-            self.image_embedding = nn.Embedding.from_pretrained(self.v_feat, freeze=False)
+            self.image_embedding = nn.Embedding.from_pretrained(in_space(self.v_feat), freeze=False)
             self.image_original = self._original_graph(
                 self.v_feat, os.path.join(dataset_path, 'image_adj_{}.pt'.format(self.knn_k)))
         if self.t_feat is not None:
-            self.text_embedding = nn.Embedding.from_pretrained(self.t_feat, freeze=False)
+            self.text_embedding = nn.Embedding.from_pretrained(in_space(self.t_feat), freeze=False)
             self.text_original = self._original_graph(
                 self.t_feat, os.path.join(dataset_path, 'text_adj_{}.pt'.format(self.knn_k)))
         if self.v_feat is not None:
@@ -90,16 +104,25 @@ class LATTICE(FusedEvalMixin, GeneralRecommender):
         val = np.power(np.bincount(rows, minlength=n).astype(np.float64), -1.0)[rows].astype(np.float32)
         return hip_ops.CsrGraph.from_coo_host(np.stack([rows, cols]), val, n, n, self.device)
 
-    def _knn_pairs(self, feats_normed):
-        knn = hip_ops.score_topk(feats_normed.detach().contiguous(), feats_normed.detach().contiguous(), self.knn_k)
+    def _knn_pairs(self, feats_normed, in_dataset_ids=False):
+        """(rows, cols) of the kNN graph of the given rows, in the id space the rows are in.  Relabelled rows are ranked in
+        the dataset's order and the pairs renamed (see __init__)."""
+        rl = self.relabelling
+        f = feats_normed.detach()
+        if rl is not None and not in_dataset_ids:
+            f = f.index_select(0, rl.perm_i)                     # row `old` of the dataset order = relabelled row perm[old]
+        knn = hip_ops.score_topk(f.contiguous(), f.contiguous(), self.knn_k)
         rows = torch.arange(self.n_items, device=knn.device).repeat_interleave(self.knn_k)
-        return rows, knn.reshape(-1)
+        cols = knn.reshape(-1)
+        if rl is not None and not in_dataset_ids:
+            rows, cols = rl.perm_i[rows], rl.perm_i[cols]
+        return rows, cols
 
-    def _weighted_knn(self, feats):
+    def _weighted_knn(self, feats, in_dataset_ids=False):
         """top-k cosine neighbours with their similarity as (differentiable) weight: build_sim +
         build_knn_neighbourhood (utils/utils.py:119-137) without the dense matrix."""
         fn = feats.div(torch.norm(feats, p=2, dim=-1, keepdim=True))
-        rows, cols = self._knn_pairs(fn)
+        rows, cols = self._knn_pairs(fn, in_dataset_ids)
         return rows, cols, (fn[rows] * fn[cols]).sum(-1)
 
     def _original_graph(self, raw_feats, cache):
@@ -107,16 +130,18 @@ class LATTICE(FusedEvalMixin, GeneralRecommender):
         (`image_adj_{k}.pt`, lattice.py:64-87): such a file is used when present, and written in that
         format when it stays under graph.DENSE_CACHE_LIMIT_BYTES."""
         from mmrec_amd.graph import DENSE_CACHE_LIMIT_BYTES, coo_to_dense_adj, dense_adj_to_coo, load_cached_adj
+        rl = self.relabelling
+        rename = (lambda r, c, v: (r, c, v)) if rl is None else (lambda r, c, v: (rl.perm_i[r], rl.perm_i[c], v))
         dense = load_cached_adj(cache)
         if dense is not None:
             rows, cols, vals = dense_adj_to_coo(dense.to(torch.float32))
-            return rows.to(self.device), cols.to(self.device), vals.to(self.device)
-        with torch.no_grad():
-            rows, cols, sim = self._weighted_knn(raw_feats.to(torch.float32))
+            return rename(rows.to(self.device), cols.to(self.device), vals.to(self.device))
+        with torch.no_grad():      # (raw_feats: the dataset's table, in the dataset's ids -- as the cache file is)
+            rows, cols, sim = self._weighted_knn(raw_feats.to(torch.float32), in_dataset_ids=True)
             vals = _sym_norm_values(rows, cols, sim, self.n_items)
         if self.n_items * self.n_items * 4 <= DENSE_CACHE_LIMIT_BYTES and os.path.isdir(os.path.dirname(cache)):
             torch.save(coo_to_dense_adj(rows, cols, vals, self.n_items), cache)
-        return rows, cols, vals
+        return rename(rows, cols, vals)
 
     def _build_item_adj(self, image_feats, text_feats):
         weight = self.softmax(self.modal_weight)
@@ -181,6 +206,7 @@ class LATTICE(FusedEvalMixin, GeneralRecommender):
         return self.forward(self.norm_adj, build_item_graph=True)
 
     def calculate_loss(self, interaction):
+        interaction = self._map_batch(interaction)
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
         ua, ia = self.forward(self.norm_adj, build_item_graph=self.build_item_graph)
         self.build_item_graph = False

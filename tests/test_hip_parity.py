@@ -25,6 +25,16 @@ def ops():
     return hip_ops
 
 
+@pytest.fixture(autouse=True)
+def _split_forward_at_every_width():
+    """hip_ops routes inputs narrower than LINEAR_SPLIT_MIN_F (1024) to the fp32-MFMA forward (fewer launches: round 6); the
+    tests of this file keep exercising the split-operand forward at EVERY width it serves, 128 and 384 included."""
+    from mmrec_amd import hip_ops
+    keep, hip_ops.LINEAR_SPLIT_MIN_F = hip_ops.LINEAR_SPLIT_MIN_F, 0
+    yield
+    hip_ops.LINEAR_SPLIT_MIN_F = keep
+
+
 def close(a, b, rtol=RTOL, atol=ATOL):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
@@ -2205,3 +2215,21 @@ def test_sharded_projection_and_topk_rccl_single_rank(ops, dev):
         assert torch.equal(a, ops.score_topk(Q, C, 20))
     finally:
         dist.destroy_process_group()
+
+
+def test_linear_narrow_inputs_take_the_fp32_forward(ops, dev):
+    """Round-5 review 3: the 384-wide text projection (freedom.py:208, bm3.py:104) is launch bound -- its forward goes to the
+    fp32-MFMA kernel (one launch) unless LINEAR_SPLIT_MIN_F says otherwise: bitwise the `hip_linear_split: False` result; the
+    4096-wide image projection keeps the split-operand kernel."""
+    g = torch.Generator().manual_seed(3)
+    for F, same in ((384, True), (4096, False)):
+        X, W, b = torch.randn(700, F, generator=g).to(dev), (torch.randn(64, F, generator=g) / F ** 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+        ops.LINEAR_SPLIT_MIN_F = 1024
+        routed = ops.linear(X, W, b)
+        try:
+            ops.LINEAR_F16X3 = False
+            fp32 = ops.linear(X, W, b)
+        finally:
+            ops.LINEAR_F16X3 = True
+        assert torch.equal(routed, fp32) == same, F
+        close(routed, (X.double() @ W.double().t() + b.double()).float(), rtol=1e-4, atol=1e-5)

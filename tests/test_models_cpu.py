@@ -463,6 +463,51 @@ def test_pgl_global_mode_spectral_subgraph(tmp_path, golden):
         get_model("PGL")(*G.setup(tmp_path / "bad2", golden, "PGL", {"mode": "nope"}, use_gpu=False)[:2])
 
 
+def test_lattice_relabelled_id_space_is_the_same_model(tmp_path, golden):
+    """`reorder` in LATTICE (lattice.py:184-195's u-i propagation, the id and feature tables, the frozen and the learned item
+    graphs): kNN neighbours are still found in the dataset's ids and the pairs renamed in order, so loss, gradients (after
+    un-permuting), evaluation scores and top-K equal the plain model's; checkpoints travel both ways."""
+    import torch
+    from mmrec_amd.utils.utils import get_model
+    res = {}
+    for key in (None, "degree"):
+        ex = {"reg_weight": 1e-3, "learning_rate": 1e-3}
+        if key:
+            ex["reorder"] = key
+        config, train_data, valid_data = G.setup(tmp_path / ("r%s" % key), golden, "LATTICE", ex, use_gpu=False)
+        model = get_model("LATTICE")(config, train_data).to("cpu")
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.pre_epoch_processing()
+        loss = model.calculate_loss(G.batch_of(golden, torch.device("cpu")))
+        loss.backward()
+        loss2 = model.calculate_loss(G.batch_of(golden, torch.device("cpu")))      # a step that does not rebuild the item graph
+        grads = {}
+        for n, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            gr, side = p.grad.clone(), model.relabelled_tables.get(n)
+            if key and side:
+                gr = gr.index_select(0, model.relabelling.perm_u if side == "u" else model.relabelling.perm_i)
+            grads[n] = gr
+        model.eval()
+        batch = next(iter(valid_data))
+        res[key] = (sd0, float(loss.detach()), grads, model.full_sort_topk(batch, 20).clone(), model.full_sort_predict(batch).clone(),
+                    model, float(loss2.detach()))
+    a, b = res[None], res["degree"]
+    assert b[5].relabelling is not None and not torch.equal(b[5].relabelling.perm_i, torch.arange(b[5].n_items))
+    assert list(a[0]) == list(b[0]) and all(torch.equal(a[0][k], b[0][k]) for k in a[0])
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(a[1]) and abs(a[6] - b[6]) <= 1e-6 * abs(a[6]), (a[1], b[1], a[6], b[6])
+    assert set(a[2]) == set(b[2])
+    for n in a[2]:
+        torch.testing.assert_close(b[2][n], a[2][n], rtol=1e-4, atol=1e-8, msg=n)
+    torch.testing.assert_close(b[4], a[4], rtol=1e-6, atol=1e-7)
+    assert torch.equal(a[3], b[3])
+    trained = {k: v + 0.01 * torch.arange(v.shape[0]).reshape([-1] + [1] * (v.dim() - 1)) if v.dim() else v for k, v in a[0].items()}
+    a[5].load_state_dict(trained), b[5].load_state_dict(trained)
+    for k, v in b[5].state_dict().items():
+        assert torch.equal(v, a[5].state_dict()[k]), k
+
+
 def test_mmgcn_relabelled_id_space_is_the_same_model(tmp_path, golden):
     """`reorder` in MMGCN (mmgcn.py:108-216): its id-indexed state is plain tensors (preference, id_embedding, the feature
     tables) and lives in the relabelled space; parameters are not id-indexed, so the state_dict is untouched.  Same draws at

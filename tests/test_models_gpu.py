@@ -1292,3 +1292,46 @@ def test_relabelled_id_space_other_plugins_on_device(tmp_path, golden, name, ext
         for n in a[2]:
             torch.testing.assert_close(b[2][n], a[2][n], rtol=1e-5, atol=1e-9, msg=n)
 
+
+
+@pytest.mark.parametrize("name,extra", [("BM3", {"n_layers": 2, "reg_weight": 0.1, "dropout": 0.3, "lazy_feature_adam": False}),
+                                        ("LATTICE", {"reg_weight": 1e-3, "learning_rate": 1e-3}),
+                                        ("MMGCN", {"reg_weight": 1e-3, "learning_rate": 1e-3})])
+def test_relabelled_id_space_rest_of_the_tier_on_device(tmp_path, golden, name, extra):
+    """Round-5 review, missing 3: config `reorder` in BM3, LATTICE and MMGCN on the device (CPU twins:
+    tests/test_models_cpu.py::test_{bm3,lattice,mmgcn}_relabelled_id_space_is_the_same_model): the same initial state_dict in
+    the dataset's row order, the plain plugin's loss (the same generator state gives the plain model's dropout masks; the
+    all-row regularisers sum in another order) and evaluation tables -- the propagation's per-row sums keep their order --, the
+    same top-K lists in the dataset's ids."""
+    if not USE_GPU:
+        pytest.skip("CPU twins in tests/test_models_cpu.py")
+    res = {}
+    for key in (None, "degree"):
+        ex = dict(extra, hip_graph_step=False)
+        if key:
+            ex["reorder"] = key
+        config, train_data, valid_data, model = build(tmp_path / ("r%s" % key), golden, name, ex)
+        assert (model.relabelling is not None) == bool(key)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.pre_epoch_processing()
+        torch.manual_seed(5)
+        loss = model.calculate_loss(batch_of(golden, model.device, rows=2 if name == "BM3" else 3))
+        loss.backward()
+        model.eval()
+        batch = next(iter(valid_data))
+        rl = model.relabelling
+        u, i = model._cached_eval_embeddings()
+        if rl is not None:
+            u, i = u.index_select(0, rl.perm_u), i.index_select(0, rl.perm_i)
+        res[key] = (sd0, float(loss.detach()), model.full_sort_topk(batch, 20).clone(), u.clone(), i.clone())
+    a, b = res[None], res["degree"]
+    assert list(a[0]) == list(b[0])
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert abs(a[1] - b[1]) <= 5e-6 * abs(a[1]), (a[1], b[1])
+    if name == "MMGCN":      # (evaluates the last TRAINING forward: dense library GEMMs in between, equal to rounding)
+        torch.testing.assert_close(b[3], a[3], rtol=1e-5, atol=1e-7), torch.testing.assert_close(b[4], a[4], rtol=1e-5, atol=1e-7)
+        assert (a[2] == b[2]).float().mean() > 0.99
+    else:
+        torch.testing.assert_close(b[3], a[3], rtol=1e-6, atol=1e-8), torch.testing.assert_close(b[4], a[4], rtol=1e-6, atol=1e-8)
+        assert (a[2] == b[2]).float().mean() > 0.999
