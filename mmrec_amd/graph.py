@@ -92,7 +92,7 @@ class BipartiteRelabelling:
     def __init__(self, base_graph, n_users, n_items, how, device):
         n = n_users + n_items
         idx, _ = base_graph.to_coo_host()
-        perm = hip_ops.locality_order(base_graph.rowptr_host, idx[1], n, how, n_left=n_users)
+        perm = hip_ops.locality_order(base_graph.rowptr_host, idx[1], n, how, n_left=n_users, device=device)
         self.how, self.n_users, self.n_items = how, int(n_users), int(n_items)
         pu = np.argsort(np.argsort(perm[:n_users], kind="stable"), kind="stable").astype(np.int64)   # rank among the users
         pi = np.argsort(np.argsort(perm[n_users:], kind="stable"), kind="stable").astype(np.int64)

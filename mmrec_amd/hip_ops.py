@@ -245,7 +245,26 @@ def _mode_labels(rows, lab_c, n_rows, n_labels):
     return out
 
 
-def locality_order(rowptr_host, colidx_host, n, how, n_left=None, iters=4):
+def _mode_labels_device(rows, lab_c, n_rows, n_labels):
+    """_mode_labels on the device (torch sorts of int64 keys: integer exact, the same answer): two sorts of nnz keys per sweep,
+    milliseconds where the numpy form takes ~1 s per sweep at 20M nonzeros (7.4 s of a config-5 model build)."""
+    key, _ = torch.sort(rows * n_labels + lab_c)
+    uk, cnt = torch.unique_consecutive(key, return_counts=True)
+    r, lab = torch.div(uk, n_labels, rounding_mode='floor'), uk % n_labels
+    cmax = int(cnt.max().item()) + 1
+    # per row: highest count first, then the smallest label -- one more sort of (row, cmax - count, label) packed in 63 bits
+    if n_rows * cmax * n_labels >= 2 ** 62:
+        raise OverflowError("label-propagation key does not fit 63 bits")
+    k2, _ = torch.sort(r * (cmax * n_labels) + (cmax - cnt) * n_labels + lab)
+    r2 = torch.div(k2, cmax * n_labels, rounding_mode='floor')
+    first = torch.ones_like(r2, dtype=torch.bool)
+    first[1:] = r2[1:] != r2[:-1]
+    out = torch.full((n_rows,), -1, dtype=torch.int64, device=rows.device)
+    out[r2[first]] = (k2 % n_labels)[first]
+    return out
+
+
+def locality_order(rowptr_host, colidx_host, n, how, n_left=None, iters=4, device=None):
     """A relabelling of the n nodes of a SQUARE graph for gather locality (round-3 review item 5): new id = perm[old id].
       'degree'     ids by descending degree (hot rows share cache lines and pages);
       'rcm'        reverse Cuthill-McKee on the structure (scipy.sparse.csgraph): good for mesh-like graphs, not for
@@ -254,7 +273,7 @@ def locality_order(rowptr_host, colidx_host, n, how, n_left=None, iters=4):
                    ordered by label: the members of a community get adjacent ids, so the rows a workgroup gathers are the
                    rows its neighbours in the grid gather.  Bipartite graphs (`n_left`: ids below it are one side) update one
                    side from the other in turn.  A graph without communities just gets some permutation.
-    Host side, integer, deterministic."""
+    Integer, deterministic; `device` (a CUDA device): the label-propagation sweeps run there (same permutation)."""
     rp = np.asarray(rowptr_host, dtype=np.int64)
     deg = np.diff(rp)
     ci = np.asarray(colidx_host, dtype=np.int64)
@@ -265,6 +284,18 @@ def locality_order(rowptr_host, colidx_host, n, how, n_left=None, iters=4):
         from scipy.sparse.csgraph import reverse_cuthill_mckee
         a = sp.csr_matrix((np.ones(ci.shape[0], dtype=np.int8), ci.astype(np.int32), rp.astype(np.int32)), shape=(n, n))
         order = np.asarray(reverse_cuthill_mckee(a, symmetric_mode=True), dtype=np.int64)
+    elif how == "community" and device is not None and torch.device(device).type == "cuda":
+        dev = torch.device(device)
+        rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=dev), torch.from_numpy(deg).to(dev))
+        cols = torch.from_numpy(ci).to(dev)
+        lab = torch.arange(n, dtype=torch.int64, device=dev)
+        sides = [None] if not n_left else [rows < n_left, rows >= n_left]
+        for _ in range(int(iters)):
+            for side in sides:                                 # (bipartite: left from right, then right from the new left)
+                r_s, c_s = (rows, cols) if side is None else (rows[side], cols[side])
+                new = _mode_labels_device(r_s, lab[c_s], n, n)
+                lab = torch.where(new >= 0, new, lab)
+        order = torch.sort(lab, stable=True)[1].cpu().numpy()      # = np.lexsort((arange(n), lab))
     elif how == "community":
         rows = np.repeat(np.arange(n, dtype=np.int64), deg)
         lab = np.arange(n, dtype=np.int64)

@@ -2233,3 +2233,23 @@ def test_linear_narrow_inputs_take_the_fp32_forward(ops, dev):
             ops.LINEAR_F16X3 = True
         assert torch.equal(routed, fp32) == same, F
         close(routed, (X.double() @ W.double().t() + b.double()).float(), rtol=1e-4, atol=1e-5)
+
+
+def test_locality_order_on_device_equals_host(ops, dev):
+    """`reorder: community` with the sweeps on the device (hip_ops.locality_order(device=...)): the permutation of the host form,
+    on a bipartite graph with planted communities and on a structureless one."""
+    from mmrec_amd import synth
+    rng = np.random.default_rng(0)
+    nu, ni, eu, ei = synth.shaped_edges("baby", seed=0)
+    r, c, v = synth.sym_norm_coo(eu, ei, nu, ni)
+    g = ops.CsrGraph.from_coo_host(np.stack([r, c]), v, nu + ni, nu + ni, dev, symmetric=True)
+    idx, _ = g.to_coo_host()
+    host = ops.locality_order(g.rowptr_host, idx[1], nu + ni, "community", n_left=nu)
+    devp = ops.locality_order(g.rowptr_host, idx[1], nu + ni, "community", n_left=nu, device=dev)
+    assert np.array_equal(host, devp) and np.array_equal(np.sort(devp), np.arange(nu + ni))
+    n = 3000                                    # a square graph (no sides) with 30 planted groups
+    grp = rng.integers(0, 30, n)
+    rows = np.repeat(np.arange(n), 8)
+    cols = np.array([rng.choice(np.flatnonzero(grp == grp[i]), 8) if rng.random() < 0.9 else rng.integers(0, n, 8) for i in range(n)]).reshape(-1)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))])
+    assert np.array_equal(ops.locality_order(rp, cols, n, "community"), ops.locality_order(rp, cols, n, "community", device=dev))

@@ -628,6 +628,22 @@ def test_bf16_three_way_split_projection_gradient_claim():
     assert np.max(np.abs(t[0] + t[1] + t[2] - tiny.astype(np.float64))) <= 2.0 ** -133
 
 
+def test_label_propagation_torch_form_equals_the_numpy_form():
+    """Round-5 review 7: `reorder: community` ran its label-propagation sweeps on the host (7.4 s of a config-5 model build);
+    hip_ops._mode_labels_device is the same integer rule -- most frequent neighbour label, ties to the smallest -- as two torch
+    sorts (run on the device when the model is there).  Here, on CPU tensors, against the numpy form; the device run is
+    tests/test_hip_parity.py::test_locality_order_on_device_equals_host."""
+    import torch
+    from mmrec_amd import hip_ops
+    rng = np.random.default_rng(3)
+    for n, nnz, n_lab in ((500, 4000, 40), (64, 2000, 3), (1000, 300, 1000)):
+        rows, cols = np.sort(rng.integers(0, n, nnz)), rng.integers(0, n, nnz)
+        lab = rng.integers(0, n_lab, n)
+        a = hip_ops._mode_labels(rows, lab[cols], n, n)
+        b = hip_ops._mode_labels_device(torch.from_numpy(rows), torch.from_numpy(lab[cols]), n, n).numpy()
+        assert np.array_equal(a, b) and (a == -1).sum() == n - np.unique(rows).shape[0]
+
+
 def test_run_configs_did_not_regress():
     """Round-5 review, next 2: MMGCN's training step once went 3.4 -> 9.5 ms per batch and no table showed it.  Every round
     commits `profiles/rNN_run_configs.json` (tools/run_config.py tier --json: Trainer-level ms per batch of VBPR and the five

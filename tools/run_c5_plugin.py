@@ -109,6 +109,17 @@ def main():
             torch.cuda.synchronize()
             log("sharded=%s: after %d more steps: %.2f ms/step over %d steps" %
                 (sharded, late, (time.time() - t) / max(len(more) - late, 1) * 1e3, len(more) - late))
+            if os.environ.get("MMREC_C5_ADAM_HIST") and not sharded:      # what the row-lazy catch-up of the NEXT step will replay
+                sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                from lazy_adam_histogram import replay_histogram
+                nxt = next(iter(train_data)).to(config["device"])
+                ids = torch.cat((nxt[1], nxt[2]))
+                if getattr(model, "relabelling", None) is not None:
+                    ids = model.relabelling.perm_i[ids]
+                for nm in ("image_embedding", "text_embedding"):
+                    emb = getattr(model, nm, None)
+                    if emb is not None and hasattr(emb, "_last_step"):
+                        replay_histogram(emb, ids, float(config["learning_rate"]), tag="[c5] lazy Adam replay, %s: " % nm)
         for which in ("first (builds the per-batch mask CSRs, cached on the loader)", "second"):
             t = time.time()
             res = trainer.evaluate(valid_data)
