@@ -938,6 +938,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run launches under rocprofv3 for roofline.traffic")
+    ap.add_argument("--no-configs", action="store_true", help="skip extra.configs_step_ms (Trainer-level epochs of VBPR and the five "
+                                                              "north_star models at their BASELINE shapes, ~1 minute)")
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed region and nothing else (no companions, no CPU baseline, no counters): what "
                          "`rocprofv3 --kernel-trace --stats -- python bench.py --headline-only` profiles, so that the summary's "
@@ -1499,6 +1501,22 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                                                                                  c[:ne] - sh.n_users)
             except Exception as ex:
                 line["extra"]["c5_train_step_roofline"] = {"error": repr(ex)}
+            if not args.no_configs:
+                # round-5 review, next 2: Trainer-level ms per batch of VBPR and the five models north_star names, at their
+                # BASELINE shapes, through the plugin API (tools/run_config.py; the committed profiles/rNN_run_configs.json of
+                # consecutive rounds are compared by tests/test_host_logic.py::test_run_configs_did_not_regress)
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import contextlib
+                    import run_config
+                    with contextlib.redirect_stdout(sys.stderr):          # (stdout carries the ONE JSON line)
+                        got = {n: run_config.run(n, None, 2, verbose=False) for n in run_config.TIER}
+                    line["extra"]["configs_step_ms"] = {n: round(v["ms_per_batch"], 4) for n, v in got.items()}
+                    line["extra"]["configs_eval_users_per_s"] = {n: round(v["eval_users_per_s"]) for n, v in got.items()}
+                    line["extra"]["configs_what"] = {n: "%s / %s-shaped synthetic data, %s" % (v["model"], v["dataset"], v["step_mode"])
+                                                     for n, v in got.items()}
+                except Exception as ex:
+                    line["extra"]["configs_step_ms"] = {"error": repr(ex)}
         if multi:
             line["extra"] = dist_extra
             line["per_rank"] = state.get("per_rank")

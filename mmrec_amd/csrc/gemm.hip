@@ -696,7 +696,8 @@ __global__ __launch_bounds__(256) void bwd_wt_split_kernel(const float* __restri
 // carry fp32's 8-bit exponent, so there is nothing to scale and nothing to guard: gradients of 1e-30 next to gradients of 1e-3
 // (a batch's BPR coefficients span 40 binades once pairs separate: measured on the Amazon-Sports-shaped FREEDOM step), features
 // of any magnitude, inf / NaN (non-finite in, non-finite out; an inf may come out as NaN: inf - bf16(inf) is NaN) all take the
-// same path.  x y = b1 c1 + (b1 c2 + b2 c1) + (b2 c2 + b1 c3 + b3 c1) + O(2^-24 |x y|): six products per 16 k (the fp16 form of
+// same path.  x y = b1 c1 + (b1 c2 + b2 c1) + (b2 c2 + b1 c3 + b3 c1) + R, |R| <= 2^-22 |x y| (the three dropped products b2 c3,
+// b3 c2, b3 c3 are each below 2^-24 |x y|; the bound every statement of this file and of mmrec_hip.h uses): six products per 16 k (the fp16 form of
 // the forward takes three, eight fp32 MFMAs take 16 x the time), one fp32 accumulator set, smallest products first.
 // The FIRST form of this kernel used the forward's two fp16 halves with one power-of-two scale per column of dY and a range
 // guard; real gradient columns leave any single scale's range within an epoch (guard at 2^26: fired on most steps, at 2^30: on
@@ -1156,7 +1157,11 @@ __global__ __launch_bounds__(320, 2) void bwd_x_f16x3_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                const float v = fmaf(cx[r], 1.f / 2048.f, hh[r]) * (rs16[r] * cinv);
+                // the two inverse scales are exact powers of two, each up to 2^+-120: where their PRODUCT leaves fp32's range
+                // (inf: an exact 0 accumulator would become NaN; 0: a finite result would vanish -- round-5 advice) they are
+                // applied one after the other instead
+                const float x = fmaf(cx[r], 1.f / 2048.f, hh[r]), sc = rs16[r] * cinv;
+                const float v = (sc != 0.f && fabsf(sc) < __builtin_inff()) ? x * sc : x * rs16[r] * cinv;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdx, (int)lane_off,
                                                       (wave * 32 + rr) * F * 4 + tcol + t * 128, STORE_AUX);
             }
@@ -1360,7 +1365,7 @@ extern "C" size_t mmrec_linear_bwd_split_workspace_bytes(int32_t n, int32_t F, i
 
 // dW [64, F] = dY^T X, db [64] = column sums of dY, dX [n, F] = dY W in ONE call (any of dW+db / dX may be NULL: not wanted).
 // out == 64 and F % 128 == 0 run the split-operand kernels; other shapes are handed to mmrec_linear_bwd_w_f32 /
-// mmrec_linear_bwd_x_f32 (same workspace).  Results: fp32-accurate (dW: error <= 2^-23 of sum |a b| per output + fp32
+// mmrec_linear_bwd_x_f32 (same workspace).  Results: fp32-accurate (dW: error <= 2^-22 of sum |a b| per output + fp32
 // accumulation, any magnitudes; dX: 2^-21 with the operands scaled into fp16's range by exact powers of two).
 extern "C" int mmrec_linear_bwd_split_f32(const float* dY, const float* X, const float* W, float* dW, float* db, float* dX,
                                           int32_t n, int32_t F, int32_t out, void* workspace, mmrec_stream_t stream) {

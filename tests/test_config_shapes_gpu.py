@@ -650,8 +650,8 @@ def test_lattice_step_vs_reference_golden_at_baby_shape(tmp_path):
     state = {"n": 0, "agree": []}
     own_pairs = latmod.LATTICE._knn_pairs
 
-    def replay(self, feats_normed):
-        rows, own = own_pairs(self, feats_normed)
+    def replay(self, feats_normed, in_dataset_ids=False):
+        rows, own = own_pairs(self, feats_normed, in_dataset_ids)
         ref = calls[state["n"] if state["n"] < 4 else 2 + state["n"] % 2].to(rows.device).reshape(-1)
         state["n"] += 1
         own_sets = own.reshape(-1, self.knn_k).sort(dim=1)[0]
