@@ -98,6 +98,14 @@ int mmrec_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float
 int mmrec_spmm_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
                         const float* Z, int32_t z_compact, const int64_t* rows, int32_t n_list, int32_t d,
                         int32_t long_row_threshold, float* Y, mmrec_stream_t stream);
+/* ABI 12: the same for ANY listed row of a d = 64 graph, rows spanning several chunks included (one workgroup per such listed
+ * row sums its chunks in the full launch's order: its bits).  max_row_chunks: the largest number of 512-nonzero chunks a row of
+ * the graph's long-row plan spans (1: identical to mmrec_spmm_rows_f32; up to 480 = 245,760 nonzeros; more: MMREC_ERR_UNSUPPORTED).
+ * For a training step that reads the LAST user-item layer (freedom.py:169-177) at its batch rows only: popular items are in
+ * every batch and their rows span dozens of chunks. */
+int mmrec_spmm_rows_any_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
+                            const float* Z, int32_t z_compact, const int64_t* rows, int32_t n_list, int32_t d,
+                            int32_t long_row_threshold, int32_t max_row_chunks, float* Y, mmrec_stream_t stream);
 int mmrec_spmm_push_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G,
                              float g_scale, const int64_t* rows, int32_t n_list, int32_t d, float* dX, float* dZ,
                              mmrec_stream_t stream);

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mmrec_bpr_fwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, _P,
                                     _P, _P, _P]),
     "mmrec_spmm_rows_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "mmrec_spmm_rows_any_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "mmrec_spmm_push_rows_f32": (c_int32, [_P, _P, _P, _P, c_float, _P, c_int32, c_int32, _P, _P, _P]),
     "mmrec_bpr_dots_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P]),
     "mmrec_bpr_loss_from_dots_f32": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P, _P, _P]),

@@ -392,6 +392,19 @@ extern "C" int mmrec_spmm_rows_f32(const int32_t* rowptr, const int32_t* colidx,
     return spmm_pull_rows_launch(rowptr, colidx, vals, X, Z, z_compact, rows, n_list, d, long_row_threshold, Y, mmrec_stream(stream));
 }
 
+// ABI 12: the same for ANY listed row of a d = 64 graph -- rows of several chunks included (max_row_chunks = the largest
+// number of MMREC_SPMM_CHUNK-nonzero chunks a row of the graph's plan spans; <= 480).
+extern "C" int mmrec_spmm_rows_any_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X,
+                                       const float* Z, int32_t z_compact, const int64_t* rows, int32_t n_list, int32_t d,
+                                       int32_t long_row_threshold, int32_t max_row_chunks, float* Y, mmrec_stream_t stream) {
+    if (d != 8 && d != 16 && d != 32 && d != 64) return MMREC_ERR_UNSUPPORTED;
+    if (n_list < 0 || long_row_threshold < 0 || max_row_chunks < 1) return MMREC_ERR_BAD_ARG;
+    if (n_list == 0) return 0;
+    if (!rowptr || !X || !rows || !Y || Y == X) return MMREC_ERR_BAD_ARG;
+    return spmm_pull_rows_launch(rowptr, colidx, vals, X, Z, z_compact, rows, n_list, d, long_row_threshold, Y, mmrec_stream(stream),
+                                 max_row_chunks);
+}
+
 extern "C" int mmrec_spmm_push_rows_f32(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G,
                                         float g_scale, const int64_t* rows, int32_t n_list, int32_t d, float* dX, float* dZ,
                                         mmrec_stream_t stream) {

@@ -10,6 +10,7 @@ int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float
 
 // listed rows only (pull, in the full launch's order) and its transpose-free atomic backward (push); d = 8 / 16 / 32 / 64
 int spmm_pull_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, const float* Z,
-                          int z_compact, const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s);
+                          int z_compact, const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s,
+                          int max_chunks = 1);
 int spmm_push_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* G, float g_scale,
                           const int64_t* rows, int n_list, int d, float* dX, float* dZ, hipStream_t s);

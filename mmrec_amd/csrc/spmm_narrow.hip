@@ -173,12 +173,13 @@ template <int LPR>
 __global__ __launch_bounds__(256) void spmm_pull_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
     const float* __restrict__ X, const float* __restrict__ Z, int z_compact, const int64_t* __restrict__ rows, int n_list,
-    int long_t, float* __restrict__ Y) {
+    int long_t, float* __restrict__ Y, int skip_multi_chunk) {
     const int t = threadIdx.x % LPR;
     const int i = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (i >= n_list) return;                                   // uniform within the sub-group
     const int row = (int)rows[i];
     const int s = rowptr[row], e = rowptr[row + 1];
+    if (skip_multi_chunk && e - s > long_t && e - s > MMREC_SPMM_CHUNK) return;      // served by spmm_pull_long_rows_kernel
     const float4* X4 = reinterpret_cast<const float4*>(X);
     float4 sum = f4_zero();
     if (e - s <= long_t) {
@@ -194,6 +195,54 @@ __global__ __launch_bounds__(256) void spmm_pull_rows_kernel(
     float4 y = f4_scale(1.f, sum);
     if (Z) y = f4_fma(1.f, reinterpret_cast<const float4*>(Z)[(size_t)(z_compact ? i : row) * LPR + t], y);
     reinterpret_cast<float4*>(Y)[(size_t)i * LPR + t] = y;
+}
+
+// Listed rows that span SEVERAL chunks (round 6: the user-item graph of a config-5 training step -- popular items are in every
+// batch), d = 64: one workgroup per listed row walks the row's chunks one after the other, each summed as its chunk block of
+// the full launch sums it (16 groups over spans of 16 nonzeros at stride 256, then the fixed-order sum over the groups), the
+// chunk partials kept in LDS and combined in reduce_long_row's order (group g: chunks g, g + 16, ... from zero; then the
+// groups in order) -- the full launch's bits for the row.  Rows of one chunk or less return at once (spmm_pull_rows_kernel
+// serves them).  Dynamic LDS: max_chunks float4[16] partials.
+__global__ __launch_bounds__(256) void spmm_pull_long_rows_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+    const float* __restrict__ X, const float* __restrict__ Z, int z_compact, const int64_t* __restrict__ rows, int n_list,
+    int long_t, int max_chunks, float* __restrict__ Y) {
+    extern __shared__ float4 s_part[];            // [max_chunks][16]
+    __shared__ float4 red[16][16];
+    const int i = blockIdx.x;
+    const int row = (int)rows[i];
+    const int s = rowptr[row], e = rowptr[row + 1];
+    if (e - s <= long_t || e - s <= MMREC_SPMM_CHUNK) return;       // uniform
+    const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n_ch = (e - s + MMREC_SPMM_CHUNK - 1) / MMREC_SPMM_CHUNK;
+    if (n_ch > max_chunks) return;                                  // (the host sized max_chunks from the graph's plan)
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    for (int c = 0; c < n_ch; ++c) {
+        const int cs = s + c * MMREC_SPMM_CHUNK, ce = min(cs + MMREC_SPMM_CHUNK, e);
+        float4 acc = f4_zero();
+        for (int base = cs + g * 16; base < ce; base += 256) gather_span<16>(colidx, vals, X4, base, min(base + 16, ce), t, acc);
+        red[g][t] = acc;
+        __syncthreads();
+        if (g == 0) {
+            float4 r = red[0][t];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) r = f4_add(r, red[k][t]);
+            s_part[c * 16 + t] = r;
+        }
+        __syncthreads();
+    }
+    float4 tsum = f4_zero();
+    for (int c = g; c < n_ch; c += 16) tsum = f4_add(tsum, s_part[c * 16 + t]);
+    red[g][t] = tsum;
+    __syncthreads();
+    if (g == 0) {
+        float4 r = red[0][t];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) r = f4_add(r, red[k][t]);
+        float4 y = f4_scale(1.f, r);
+        if (Z) y = f4_fma(1.f, reinterpret_cast<const float4*>(Z)[(size_t)(z_compact ? i : row) * 16 + t], y);
+        reinterpret_cast<float4*>(Y)[(size_t)i * 16 + t] = y;
+    }
 }
 
 // The transpose-free backward of the above: dX[c] += A[r, c] * G[i] for every nonzero (r, c) of the listed rows r = rows[i]
@@ -263,10 +312,15 @@ int spmm_narrow_launch(const int32_t* rowptr, const int32_t* colidx, const float
 }
 
 int spmm_pull_rows_launch(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* X, const float* Z,
-                          int z_compact, const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s) {
+                          int z_compact, const int64_t* rows, int n_list, int d, int long_t, float* Y, hipStream_t s,
+                          int max_chunks) {
+    // max_chunks > 1: the graph has rows of several chunks; the listed ones among them get a workgroup each (d = 64 only)
+    const int skip = max_chunks > 1 ? 1 : 0;
+    if (skip && d != 64) return MMREC_ERR_UNSUPPORTED;
+    if (skip && (size_t)max_chunks * 256 > 120 * 1024) return MMREC_ERR_UNSUPPORTED;      // the row's partials live in LDS
 #define MMREC_PULL(L)                                                                                                     \
     hipLaunchKernelGGL(spmm_pull_rows_kernel<L>, dim3((n_list + 256 / L - 1) / (256 / L)), dim3(256), 0, s, rowptr, colidx, vals, \
-                       X, Z, z_compact, rows, n_list, long_t, Y)
+                       X, Z, z_compact, rows, n_list, long_t, Y, skip)
     switch (d) {
         case 8: MMREC_PULL(2); break;
         case 16: MMREC_PULL(4); break;
@@ -275,6 +329,16 @@ int spmm_pull_rows_launch(const int32_t* rowptr, const int32_t* colidx, const fl
         default: return MMREC_ERR_UNSUPPORTED;
     }
 #undef MMREC_PULL
+    if (skip) {
+        const size_t lds = (size_t)max_chunks * 256;
+        if (lds > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_pull_long_rows_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(spmm_pull_long_rows_kernel, dim3(n_list), dim3(256), lds, s, rowptr, colidx, vals, X, Z, z_compact, rows,
+                           n_list, long_t, max_chunks, Y);
+    }
     return (int)hipGetLastError();
 }
 

@@ -146,11 +146,13 @@ class CsrGraph:
                                                 cp.ctypes.data_as(ctypes.c_void_p)), "spmm_plan_fill")
             self.long_rows = torch.from_numpy(lr).to(dev)
             self.long_chunk_ptr = torch.from_numpy(cp).to(dev)
+            self.max_row_chunks = int(np.diff(cp).max())          # chunks of the longest row (mmrec_spmm_rows_any_f32)
             # last-arriver counters of the multi-chunk rows (small graphs finish such a row inside the launch): zero now,
             # left at zero by every launch
             self.long_tickets = torch.zeros(self.n_long, dtype=torch.int32, device=dev)
         else:
             self.long_rows = self.long_chunk_ptr = self.long_tickets = None
+            self.max_row_chunks = 1
         self._partials = {}
 
     def checked(self, rc, what):
@@ -363,10 +365,15 @@ def spmm_raw(g: CsrGraph, X, Y=None, Z=None, acc_in=None, acc_out=None, alpha=1.
     return Y if Y is not None else acc_out
 
 
+ROWS_MAX_CHUNKS = 480      # mmrec_spmm_rows_any_f32 keeps a listed row's chunk partials in LDS (256 B each)
+
+
 def rows_servable(g: CsrGraph, d):
-    """can mmrec_spmm_rows_f32 reproduce the full launch's bits on this graph?  (no row spanning several chunks; a width the
-    row-list kernels have)"""
-    return g.n_chunks == g.n_long and d in SLICE_WIDTHS + (EMB_DIM,)
+    """can the row-list kernels reproduce the full launch's bits on this graph?  Every width they have when no row spans
+    several chunks (mmrec_spmm_rows_f32); d = 64 also with such rows, up to ROWS_MAX_CHUNKS chunks (mmrec_spmm_rows_any_f32)"""
+    if d not in SLICE_WIDTHS + (EMB_DIM,):
+        return False
+    return g.n_chunks == g.n_long or (d == EMB_DIM and g.max_row_chunks <= ROWS_MAX_CHUNKS)
 
 
 def spmm_rows_raw(g: CsrGraph, X, rows, Z=None, z_compact=False):
@@ -381,9 +388,13 @@ def spmm_rows_raw(g: CsrGraph, X, rows, Z=None, z_compact=False):
     if Z is not None and (_chk(Z, torch.float32, "Z", 2).shape[0] < (rows.numel() if z_compact else g.n_rows) or Z.shape[1] != d):
         raise _lib.MMRecHipError("Z must be [>=%d, %d]" % (rows.numel() if z_compact else g.n_rows, d))
     Y = torch.empty(rows.numel(), d, dtype=torch.float32, device=X.device)
-    _lib.check(lib.mmrec_spmm_rows_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Z), 1 if z_compact else 0, _p(rows),
-                                       rows.numel(), d, g.long_row_threshold if g.n_long > 0 else 2 ** 31 - 1, _p(Y),
-                                       _stream()), "spmm_rows_f32")
+    long_t = g.long_row_threshold if g.n_long > 0 else 2 ** 31 - 1
+    if g.n_chunks == g.n_long:
+        _lib.check(lib.mmrec_spmm_rows_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Z), 1 if z_compact else 0, _p(rows),
+                                           rows.numel(), d, long_t, _p(Y), _stream()), "spmm_rows_f32")
+    else:       # rows of several chunks among the graph's: a workgroup per such listed row (ABI 12)
+        _lib.check(lib.mmrec_spmm_rows_any_f32(_p(g.rowptr), _p(g.colidx), _p(g.vals), _p(X), _p(Z), 1 if z_compact else 0, _p(rows),
+                                               rows.numel(), d, long_t, g.max_row_chunks, _p(Y), _stream()), "spmm_rows_any_f32")
     return Y
 
 
@@ -565,6 +576,9 @@ def lightgcn_mean_parts(g: CsrGraph, parts, n_layers):
     return _LightGCNMeanParts.apply(g, n_layers, *parts)
 
 
+ROWS_LAST_LAYER = True      # lightgcn_mean_parts_rows: last layer at the listed rows only (False: full launches + gather, A/B)
+
+
 class _LightGCNMeanPartsRows(torch.autograd.Function):
     """lightgcn_mean_parts consumed at LISTED rows only (the batch's users and items): the forward is the full propagation
     (every layer feeds the next) followed by a gather of the listed rows; the BACKWARD starts from the compact gradient of those
@@ -580,8 +594,25 @@ class _LightGCNMeanPartsRows(torch.autograd.Function):
             E0 = parts[0].detach().as_strided((sum(ctx.sizes), parts[0].shape[1]), (parts[0].shape[1], 1))
         else:
             E0 = torch.cat([p.detach() for p in parts], dim=0)
-        out = _LightGCNMean.forward(ctx, E0, g, n_layers)
         ctx.save_for_backward(rows)
+        L = int(n_layers)
+        if L >= 1 and ROWS_LAST_LAYER and rows_servable(g, E0.shape[1]) and E0.shape[0] == g.n_rows == g.n_cols:
+            # Round 6: the LAST layer is read at the listed rows only -- it feeds no further layer -- so it is computed there
+            # (spmm_rows_raw: the full launch's bits row by row, long rows included), with the epilogue's
+            # s * (running layer sum + y) done on the compact rows: a launch over all rows less per step (0.30 of a
+            # config-5 step's 2.35 ms).
+            ctx.g, ctx.L = g, L
+            E0 = E0.contiguous()
+            cur, acc = E0, E0
+            if L > 1:
+                acc = torch.empty_like(E0)
+                bufs = [torch.empty_like(E0), torch.empty_like(E0) if L > 2 else None]
+                for layer in range(1, L):
+                    Y = bufs[(layer - 1) % 2]
+                    spmm_raw(g, cur, Y=Y, acc_in=E0 if layer == 1 else acc, acc_out=acc, acc_scale=1.0)
+                    cur = Y
+            return spmm_rows_raw(g, cur, rows, Z=acc) * (1.0 / (L + 1))
+        out = _LightGCNMean.forward(ctx, E0, g, n_layers)
         return out.index_select(0, rows)
 
     @staticmethod

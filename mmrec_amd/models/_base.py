@@ -110,6 +110,8 @@ class FusedEvalMixin:
     eval_hint = True
     _hint = None
     HINT_STALE_FRAC = 0.02      # more than this share of an evaluation's queries in the overflow / slow queues: next one is cold
+    HINT_PROBE_FRAC = 0.005     # ... and of the FIRST warm batch of a pass (large candidate sets): the rest of the pass is cold
+    HINT_PROBE_MIN_CANDIDATES = 32768
 
     def _ranked_with_hint(self, interaction, users, q, cands, k, rowptr, cols):
         import numpy as np
@@ -134,12 +136,21 @@ class FusedEvalMixin:
         # a list exists for every user of the batch; after a pass whose lists had gone stale (eval_hint_feedback) only lists
         # written under the CURRENT tables count (the TEST pass after a cold VALID pass), until a cold pass has refreshed them
         oldest = int(st['ver'][users_np].min()) if users_np.shape[0] else 0
-        warm = oldest > 0 and (oldest >= st['cold_from'] or oldest == self._tables_version)
+        old_lists = oldest != self._tables_version       # lists of EARLIER tables: the ones that can be stale
+        warm = oldest > 0 and (oldest >= st['cold_from'] or not old_lists) and not (old_lists and st.get('pass_cold'))
         # either way the call leaves its ranking (top-k + the runners-up it ranked) in the users' rows for the next one
         out = hip_ops.score_topk(q, cands, k, rowptr, cols, hint=st['table'], hint_rows=users, hint_cold=not warm,
                                  queue_counts=st['counts'] if warm else None)
-        if warm and oldest != self._tables_version:      # lists of EARLIER tables: the ones that can be stale
+        if warm and old_lists:
             st['queries'] += users_np.shape[0]
+            # PROBE: against a large candidate set a query whose list has gone useless costs an exact scan of all candidates
+            # (config 5, 200 training steps after the previous evaluation: 4.6 % of the users, 0.42 s for a pass that takes
+            # 0.09 s cold).  The first warm batch of a pass tells: one 8-byte read, and the rest of the pass runs cold (and
+            # refreshes the lists) when more than HINT_PROBE_FRAC of its queries needed the queues.
+            if nc >= self.HINT_PROBE_MIN_CANDIDATES and not st.get('probed'):
+                st['probed'] = True
+                slow, over = st['counts'].tolist()
+                st['pass_cold'] = (slow + over) > self.HINT_PROBE_FRAC * st['queries']
         st['warm' if warm else 'cold'] += 1
         st['ver'][users_np] = self._tables_version
         return out
@@ -155,9 +166,11 @@ class FusedEvalMixin:
         if st['queries']:                                # warm queries ranked from lists of earlier tables
             slow, over = st['counts'].tolist()
             stale = (slow + over) > self.HINT_STALE_FRAC * st['queries']
-            st['cold_from'] = self._tables_version + 1 if stale else 0
+            # (a pass the probe turned cold has refreshed every list itself: the next evaluation probes again)
+            st['cold_from'] = self._tables_version + 1 if (stale and not st.get('pass_cold')) else 0
             st['last_queues'] = (slow, over, st['queries'])
         st['counts'].zero_()
+        st['probed'] = st['pass_cold'] = False
         done = (st['warm'], st['cold'])
         st['warm'] = st['cold'] = st['queries'] = 0
         return done

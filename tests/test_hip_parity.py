@@ -464,12 +464,53 @@ def test_spmm_listed_rows_pull_is_bitwise_the_full_launch_and_push_is_its_transp
     zc = ops.spmm_rows_raw(g, X, rows, Z=G, z_compact=True)   # a compact residual: + Z[i]
     plain = ops.spmm_rows_raw(g, X, rows)
     assert torch.equal(zc, plain + G)
-    # a graph with a row spanning several chunks is not served: the caller keeps the full launch
+    # a graph with a row spanning several chunks: served at d = 64 since ABI 12 (mmrec_spmm_rows_any_f32, next test); the
+    # narrower widths keep the full launch
     big = ops.CsrGraph.from_coo_host(np.stack([np.zeros(2000, np.int64), rng.integers(0, 3000, 2000)]),
                                      np.ones(2000, np.float32), 3000, 3000, dev, long_row_threshold=None)
-    assert not ops.rows_servable(big, d)
-    with pytest.raises(Exception):
-        ops.spmm_rows_raw(big, X[:3000].contiguous(), rows[:10] % 3000)
+    assert ops.rows_servable(big, d) == (d == 64)
+    if d != 64:
+        with pytest.raises(Exception):
+            ops.spmm_rows_raw(big, X[:3000].contiguous(), rows[:10] % 3000)
+
+
+def test_spmm_listed_rows_spanning_several_chunks_are_bitwise_the_full_launch(ops, dev):
+    """mmrec_spmm_rows_any_f32 (ABI 12; the LAST user-item layer of a training step read at its batch rows, freedom.py:169-177 +
+    197-199: popular items are in every batch and their rows span dozens of 512-nonzero chunks): rows of 2 ... 254 chunks,
+    single-chunk long rows and short rows, listed several times and out of order, with the full and the compact residual --
+    the full launch's bits for every listed row; the layer mean read at such rows (hip_ops.lightgcn_mean_parts_rows, last
+    layer at the rows only) equals the full propagation read there, bit for bit, and its A/B switch reproduces the old path."""
+    rng = np.random.default_rng(12)
+    n = 40_000
+    degs = rng.integers(0, 40, n)
+    hubs = {7: 130_000, 8: 513, 9: 1024, 100: 1025, 101: 30_000, 39_999: 5_000, 20_000: 512}
+    for r, k in hubs.items():
+        degs[r] = k
+    rows_coo = np.repeat(np.arange(n), degs)
+    cols = rng.integers(0, n, rows_coo.shape[0])
+    vals = rng.standard_normal(rows_coo.shape[0]).astype(np.float32) * 0.1
+    g = ops.CsrGraph.from_coo_host(np.stack([rows_coo, cols]), vals, n, n, dev)
+    assert g.n_chunks > g.n_long and g.max_row_chunks == -(-130_000 // 512) and ops.rows_servable(g, 64)
+    X = D(rng.standard_normal((n, 64)).astype(np.float32), dev)
+    Z = D(rng.standard_normal((n, 64)).astype(np.float32), dev)
+    listed = torch.from_numpy(np.concatenate([list(hubs), rng.integers(0, n, 2000), [7, 101, 7, 0, n - 1]])).to(dev)
+    for z in (None, Z):
+        full = torch.empty(n, 64, device=dev)
+        ops.spmm_raw(g, X, Y=full, Z=z)
+        assert torch.equal(ops.spmm_rows_raw(g, X, listed, Z=z), full[listed])
+    Gc = D(rng.standard_normal((listed.numel(), 64)).astype(np.float32), dev)
+    assert torch.equal(ops.spmm_rows_raw(g, X, listed, Z=Gc, z_compact=True), ops.spmm_rows_raw(g, X, listed) + Gc)
+    # the layer mean at listed rows (a square graph used as its own "user-item" graph: two row blocks)
+    a, b = X[:n // 2].contiguous(), X[n // 2:].contiguous()
+    for L in (1, 2, 3):
+        want = torch.cat(ops.lightgcn_mean_parts(g, (a, b), L), dim=0)[listed]
+        got = ops.lightgcn_mean_parts_rows(g, (a, b), L, listed)
+        assert torch.equal(got, want), L
+        try:
+            ops.ROWS_LAST_LAYER = False
+            assert torch.equal(ops.lightgcn_mean_parts_rows(g, (a, b), L, listed), want)
+        finally:
+            ops.ROWS_LAST_LAYER = True
 
 
 @pytest.mark.parametrize("d", [64, 16])

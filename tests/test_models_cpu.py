@@ -289,6 +289,26 @@ def test_warm_evaluation_state_machine(tmp_path, golden, monkeypatch):
     model.train(), model.eval()
     calls.clear(), trainer.evaluate(valid_data)      # the refreshed lists serve the next tables without crowding: demand lifted
     assert trainer.eval_warm == (n_batches, 0) and model._hint["cold_from"] == 0
+    # the PROBE of large candidate sets: the first warm batch of a pass reports its queues; crowded -> the rest of the pass
+    # runs cold (refreshing the lists), and the next evaluation simply probes again
+    model.HINT_PROBE_MIN_CANDIDATES = 0
+    valid_data.step = 64                             # several batches per pass
+    valid_data.pr = 0
+    valid_data._batch_cache.clear()                  # (derived data of the one-batch form)
+    n_b = -(-valid_data.pr_end // 64)
+    assert n_b > 2
+    model.train(), model.eval()
+    spy.crowd = True
+    calls.clear(), trainer.evaluate(valid_data)
+    assert trainer.eval_warm == (1, n_b - 1) and calls[0] is not None and all(c is None for c in calls[1:])
+    assert model._hint["cold_from"] == 0
+    spy.crowd = False
+    calls.clear(), trainer.evaluate(valid_data)      # same tables: fresh lists, warm, no probe
+    assert trainer.eval_warm == (n_b, 0)
+    model.train(), model.eval()
+    calls.clear(), trainer.evaluate(valid_data)      # new tables, quiet queues: the probe passes, every batch warm
+    assert trainer.eval_warm == (n_b, 0)
+    del model.HINT_PROBE_MIN_CANDIDATES
     config["hip_eval_hint"] = False
     t2 = Trainer(config, model)
     monkeypatch.setattr(hip_ops, "score_topk", real)
