@@ -18,7 +18,6 @@ class GraphedTrainStep:
         self.loss_func = loss_func or model.calculate_loss
         self.graph = None
         self.static_batch = None
-        self.static_next = None                      # the batch after it (one step of lookahead for the plugin's `lookahead` hook)
         self.static_loss = None
         self._warm = False
         self.failed = False
@@ -27,21 +26,8 @@ class GraphedTrainStep:
         """Call when buffers the step reads were re-created (new epoch / rebuilt graph)."""
         self.graph = None
 
-    def _set_next(self, upcoming):
-        """the lookahead buffer of the captured step: the next batch's ids, or -1 ("no row") when there is none / it has another
-        shape (the short last batch of an epoch)"""
-        if self.static_next is None:
-            return
-        if upcoming is not None and upcoming.shape == self.static_next.shape:
-            self.static_next.copy_(upcoming)
-        else:
-            self.static_next.fill_(-1)
-
     def _capture(self, batch):
         self.static_batch = batch.clone()
-        if hasattr(self.model, 'lookahead'):
-            self.static_next = torch.full_like(batch, -1)
-            self.model.lookahead(self.static_next)
         import inspect
         try:                                         # does this optimizer reserve per-capture room for row-lazy tables?
             takes_steps = len(inspect.signature(self.opt.init_state).parameters) >= 1
@@ -61,19 +47,19 @@ class GraphedTrainStep:
             self.opt.step()
         self.graph, self.static_loss = g, loss
 
-    def __call__(self, batch, upcoming=None):
-        """Runs one optimizer step on `batch`; returns the (static) loss tensor.  `upcoming`: the batch after it, if known."""
+    def __call__(self, batch):
+        """Runs one optimizer step on `batch`; returns the (static) loss tensor."""
         if not self._warm:
             # the very first step runs eagerly: library GEMMs (rocBLAS / hipBLASLt behind the 64x64
             # gate / predictor layers of BM3, LATTICE, MMGCN, MGCN) create handles and workspaces on
             # first use, which is not permitted while a stream is capturing
             self._warm = True
-            return self._eager(batch, upcoming)
+            return self._eager(batch)
         if self.failed:
-            return self._eager(batch, upcoming)
+            return self._eager(batch)
         if self.graph is None or batch.shape != self.static_batch.shape:
             if self.graph is not None and batch.shape != self.static_batch.shape:
-                return self._eager(batch, None)      # the short last batch of an epoch
+                return self._eager(batch)            # the short last batch of an epoch
             try:
                 self._capture(batch)
             except Exception as ex:                  # something in this model's step cannot be captured: run eagerly
@@ -81,17 +67,14 @@ class GraphedTrainStep:
                 logging.getLogger().warning('hipGraph capture of the training step failed (%r); continuing eagerly' % (ex,))
                 self.failed, self.graph = True, None
                 torch.cuda.synchronize()
-                return self._eager(batch, upcoming)
+                return self._eager(batch)
         else:
             self.static_batch.copy_(batch)
-        self._set_next(upcoming)
         self.opt.sync_lr()
         self.graph.replay()
         return self.static_loss
 
-    def _eager(self, batch, upcoming=None):
-        if hasattr(self.model, 'lookahead'):
-            self.model.lookahead(upcoming)
+    def _eager(self, batch):
         self.opt.zero_grad(set_to_none=True)
         losses = self.loss_func(batch)
         loss = sum(losses) if isinstance(losses, tuple) else losses

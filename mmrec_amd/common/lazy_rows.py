@@ -88,8 +88,6 @@ class LazyRowEmbedding(nn.Embedding):
         self._dev = None                        # (step_dev int64[1], hyper_dev fp32[2]) of a capturable HipAdam: graph replay
         self._overflow = None                   # device flag: a step beyond the capacity of `_hist` (checked per epoch)
         self._prefetched = None                 # (ids, event) of a catch-up running on the side stream
-        self._ahead = None                      # event of a LOOKAHEAD catch-up (the next step's rows) on the side stream
-        self._snap = None                       # device copy of the optimizer's step counter taken when it was issued
         self.allow_missing = False              # True: rows(ids) accepts -1 = "no row" (item-sharded tables: slots of other ranks)
 
     # ---- device state, created on first use (the module may have been moved since construction)
@@ -145,9 +143,8 @@ class LazyRowEmbedding(nn.Embedding):
             raise _lib.MMRecHipError("row-lazy Adam: more replayed optimizer steps than reserve() made room for; the "
                                      "feature table is not up to date (GraphedTrainStep reserves per epoch)")
 
-    def _catch_up(self, ids, step_dev=None):
-        """rows of `ids` (None: all) -> state after the `self._t` optimizer steps taken so far (graph replay: after the steps
-        the device counter `step_dev`, default the optimizer's own, holds when the kernel runs)"""
+    def _catch_up(self, ids):
+        """rows of `ids` (None: all) -> state after the `self._t` optimizer steps taken so far"""
         if self._opt is None or (self._t == 0 and self._dev is None):
             return
         w = self._state()
@@ -159,8 +156,8 @@ class LazyRowEmbedding(nn.Embedding):
         if self._dev is not None:
             _lib.check(lib.mmrec_adam_rows_catchup_dev_f32(
                 _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
-                w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._hist.shape[0],
-                _p(self._dev[0] if step_dev is None else step_dev), b1, b2, eps, wd, _stream()), "adam_rows_catchup_dev")
+                w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._hist.shape[0], _p(self._dev[0]), b1, b2,
+                eps, wd, _stream()), "adam_rows_catchup_dev")
             return
         _lib.check(lib.mmrec_adam_rows_catchup_f32(
             _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
@@ -185,40 +182,6 @@ class LazyRowEmbedding(nn.Embedding):
             done.record(side)
         self._prefetched = (ids, done)
 
-    def prefetch_ahead(self, ids_next):
-        """Round 6: start the catch-up of the NEXT step's rows now.  Late in a run a touched row has ~n_rows / rows-per-step
-        optimizer steps to replay -- arithmetic, 1.2 ms per config-5 step for the two feature tables -- and the replay of the
-        CURRENT step's rows only has the forward propagation to hide under before the projection needs them.  A caller that
-        knows the next batch (the Trainer looks one batch ahead) issues that batch's replay one step early: it runs on the side
-        stream under this step's loss, backward and dense Adam, and the next step's own catch-up finds one step left to replay
-        per row.  Same per-row sequence of updates (a row is replayed to the steps taken when THIS call is issued: the step
-        counter is snapshotted on the calling stream -- the optimizer increments it later in the step), hence the same bits.
-        Rows that are also in the current batch were caught up by `prefetch` / `rows` just before (same side stream) and are
-        skipped.  `_apply_step` waits for it (the two share the owner marks).  ids < 0: no row."""
-        if self._opt is None or (self._t == 0 and self._dev is None) or ids_next is None or not ids_next.is_cuda:
-            return
-        if torch.cuda.is_current_stream_capturing() and not PREFETCH_IN_CAPTURE:
-            return
-        ids_next = ids_next.contiguous()
-        snap = None
-        if self._dev is not None:
-            if self._snap is None or self._snap.device != ids_next.device:
-                self._snap = torch.zeros(1, dtype=torch.int64, device=ids_next.device)
-            self._snap.copy_(self._dev[0])               # on the calling stream: the steps taken so far
-            snap = self._snap
-        side = _side_stream(ids_next.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            self._catch_up(ids_next, step_dev=snap)
-            done = torch.cuda.Event()
-            done.record(side)
-        self._ahead = done
-
-    def _join_ahead(self):
-        if self._ahead is not None:
-            torch.cuda.current_stream().wait_event(self._ahead)
-            self._ahead = None
-
     def rows(self, ids):
         """up-to-date rows `ids` [len(ids), F], differentiable w.r.t. the table"""
         ids = ids.contiguous()
@@ -239,13 +202,11 @@ class LazyRowEmbedding(nn.Embedding):
         """apply every postponed update: afterwards `weight` (and the moments) equal dense Adam's"""
         if self._dev is not None:
             self.check_overflow()
-        self._join_ahead()
         self._catch_up(None)
 
     # ---- called by HipAdam.step()
     @torch.no_grad()
     def _apply_step(self, lr, b1, b2, eps, wd):
-        self._join_ahead()                      # a lookahead catch-up shares the owner marks with the step below
         if not self._pending:
             if self._dev is not None and self.steps_on_device() > 0:
                 # the device step counter is the optimizer's: a step that skips this table would leave a hole in its

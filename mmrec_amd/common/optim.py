@@ -124,12 +124,18 @@ class HipAdam(torch.optim.Optimizer):
                     lr_dev.fill_(float(group['lr']))
                 _lib.check(lib.mmrec_adam_prepare(_ptr(step_dev), _ptr(lr_dev), float(b1), float(b2),
                                                   _ptr(hyper), stream), "adam_prepare")
-            todo, lazy = [], []
+            todo = []
             for p in group['params']:
                 table = getattr(p, '_lazy_table', None)
                 if table is not None:   # row-lazy exact Adam (common/lazy_rows.py): only the touched rows are visited
-                    lazy.append((p, table))             # ... AFTER the dense tensors of the group (below): a lookahead
-                    continue                            # catch-up (LazyRowEmbedding.prefetch_ahead) runs under their launch
+                    st = self._moments(p)
+                    table._bind(st['exp_avg'], st['exp_avg_sq'],
+                                (float(b1), float(b2), float(group['eps']), float(group['weight_decay'])),
+                                dev=(step_dev, hyper) if self.capturable else None)
+                    if table._apply_step(group['lr'], float(b1), float(b2), float(group['eps']),
+                                         float(group['weight_decay'])):
+                        st['step'] += 1
+                    continue
                 if p.grad is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
@@ -138,17 +144,7 @@ class HipAdam(torch.optim.Optimizer):
                 st['step'] += 1   # host mirror (exact outside graph replays)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 todo.append((p, g, st))
-            def lazy_steps():
-                for p, table in lazy:
-                    st = self._moments(p)
-                    table._bind(st['exp_avg'], st['exp_avg_sq'],
-                                (float(b1), float(b2), float(group['eps']), float(group['weight_decay'])),
-                                dev=(step_dev, hyper) if self.capturable else None)
-                    if table._apply_step(group['lr'], float(b1), float(b2), float(group['eps']),
-                                         float(group['weight_decay'])):
-                        st['step'] += 1
             if not todo:
-                lazy_steps()
                 continue
             if not self.multi_tensor:
                 for p, g, st in todo:
@@ -162,7 +158,6 @@ class HipAdam(torch.optim.Optimizer):
                             _ptr(p), _ptr(g), _ptr(st['exp_avg']), _ptr(st['exp_avg_sq']), p.numel(),
                             float(group['lr']), float(b1), float(b2), float(group['eps']),
                             float(group['weight_decay']), int(st['step']), stream), "adam_step")
-                lazy_steps()
                 continue
             # one launch for the whole group: host arrays of device pointers, copied into the kernel arguments
             k = len(todo)
@@ -180,5 +175,4 @@ class HipAdam(torch.optim.Optimizer):
                 _lib.check(lib.mmrec_adam_multi_step_f32(
                     pp, gg, mm, vv, nn_, k, lrs, steps, float(b1), float(b2), float(group['eps']),
                     float(group['weight_decay']), stream), "adam_multi_step")
-            lazy_steps()
         return loss

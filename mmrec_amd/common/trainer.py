@@ -133,26 +133,15 @@ class Trainer(AbstractTrainer):
                 graphed.steps_per_capture = len(train_data) + 2
             except TypeError:
                 graphed.steps_per_capture = None
-        # ONE batch of lookahead (round 6): a plugin with row-lazy feature tables starts the NEXT batch's row catch-up during
-        # this step (`lookahead` hook; LazyRowEmbedding.prefetch_ahead) -- the loader is asked for batch t + 1 before step t
-        # runs, in the same order as before, so ids and sampled negatives are unchanged
-        looks_ahead = hasattr(self.model, 'lookahead')
-        batches = iter(train_data)
-        upcoming = next(batches, None)
-        batch_idx = -1
-        while upcoming is not None:
-            interaction, upcoming = upcoming, next(batches, None)
-            batch_idx += 1
+        for batch_idx, interaction in enumerate(train_data):
             if graphed is not None:
-                per_batch.append(graphed(interaction, upcoming if looks_ahead else None).detach().clone())
+                per_batch.append(graphed(interaction).detach().clone())
                 if (batch_idx + 1) % self.NAN_CHECK_EVERY == 0:      # the same probe as the eager path below
                     if bool(torch.isnan(torch.stack(per_batch[-self.NAN_CHECK_EVERY:])).any()):
                         break
                 continue
             self.optimizer.zero_grad()
             replay = interaction.clone() if self.mg else None     # only the Mirror-Gradient variant reuses the batch
-            if looks_ahead:
-                self.model.lookahead(upcoming)
             losses = loss_func(interaction)
             loss = self._total(losses)
             if isinstance(losses, tuple):

@@ -69,12 +69,6 @@ class BM3(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecomm
             self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
             nn.init.xavier_normal_(self.text_trs.weight)
 
-    _next_interaction = None
-
-    def lookahead(self, next_interaction):
-        """the Trainer looks one batch ahead (common/trainer.py): [2, B] ids of the batch after this one, None / -1 = none"""
-        self._next_interaction = next_interaction
-
     def forward(self):
         u, i = hip_ops.lightgcn_mean_parts(self.norm_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
                                            self.n_layers)
@@ -107,16 +101,10 @@ class BM3(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecomm
 
     def calculate_loss(self, interactions):
         if self.lazy_projection and self.lazy_feature_adam and self.lazy_prefetch:   # row catch-up on the side stream
-            rl = self.relabelling
-            rows_pf = interactions[1] if rl is None else rl.perm_i[interactions[1]]
-            ahead = self._next_interaction[1] if self._next_interaction is not None else None    # the Trainer's lookahead
-            if ahead is not None and rl is not None:
-                ahead = torch.where(ahead >= 0, rl.perm_i[ahead.clamp_min(0)], ahead)
+            rows_pf = interactions[1] if self.relabelling is None else self.relabelling.perm_i[interactions[1]]
             for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
                 if emb is not None:
                     emb.prefetch(rows_pf)
-                    if ahead is not None:                   # the NEXT batch's rows: replayed under the rest of this step
-                        emb.prefetch_ahead(ahead)
         items_ds = interactions[1]                  # the dataset's ids: what the per-item dropout masks are indexed with
         interactions = self._map_batch(interactions)
         u_ori, i_ori = self.forward()

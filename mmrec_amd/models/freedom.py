@@ -169,12 +169,9 @@ class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRe
         if self.lazy_projection:
             rows = torch.cat((pos_items, neg_items))
             if self.lazy_feature_adam and self.lazy_prefetch:      # the row catch-up streams through HBM under the propagation
-                ahead = self._rows_of_next_batch()
                 for emb in (getattr(self, 'text_embedding', None), getattr(self, 'image_embedding', None)):
                     if emb is not None:
                         emb.prefetch(rows)
-                        if ahead is not None:                      # ... and the NEXT batch's rows under the rest of this step
-                            emb.prefetch_ahead(ahead)
         if self.lazy_projection and self.pull_batch_rows and self.n_layers == 1 and not hip_ops.DETERMINISTIC:
             return self._loss_at_batch_rows(users, pos_items, neg_items, rows)
         ua, ia = self.forward(self.masked_adj)
@@ -196,24 +193,6 @@ class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRe
             image_feats = hip_ops.linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
             mf_v = hip_ops.bpr_loss(ua, image_feats, users, pos_items, neg_items)
         return loss + self.reg_weight * (mf_t + mf_v)
-
-    # The Trainer looks one batch ahead (common/trainer.py: `lookahead` hook): the [3, B] ids of the batch after this one, None
-    # when there is none; under a captured step a static buffer whose ids are -1 ("no row") when there is none.
-    _next_interaction = None
-
-    def lookahead(self, next_interaction):
-        self._next_interaction = next_interaction
-
-    def _rows_of_next_batch(self):
-        """feature-table rows (pos ++ neg items, in the id space the tables live in) the NEXT step will gather, -1 = no row"""
-        nxt = self._next_interaction
-        if nxt is None or nxt.shape[0] < 3:
-            return None
-        ids = torch.cat((nxt[1], nxt[2]))
-        rl = self.relabelling
-        if rl is None:
-            return ids
-        return torch.where(ids >= 0, rl.perm_i[ids.clamp_min(0)], ids)
 
     def _batch_terms(self, first_table, first_pos, first_neg, rows):
         """the three BPR terms: (id table or rows, pos ids, neg ids) + the projections of the batch's <= 2B feature rows"""
