@@ -9,6 +9,12 @@
 #ifndef MMREC_ADAM_NO_SETTLED    // probe build (-DMMREC_ADAM_NO_SETTLED=1; profiles/r04_c5_steady_state_settled_replay_ab.log): the catch-up always replays the full element-step
 #define MMREC_ADAM_NO_SETTLED 0
 #endif
+#ifndef MMREC_ADAM_ILP
+#define MMREC_ADAM_ILP 1      // float4 groups per thread and trip of the dense multi-tensor kernel
+#endif
+#ifndef MMREC_ADAM_NT
+#define MMREC_ADAM_NT 0       // (with ILP >= 2) non-temporal loads of g / m / v and stores of m / v
+#endif
 
 namespace {
 
@@ -132,7 +138,39 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable tab, co
     const size_t nb = tab.block_start[ti + 1] - tab.block_start[ti];
     const size_t b = blockIdx.x - tab.block_start[ti];
     const size_t n4 = d.n / 4, stride = nb * 256;
-    for (size_t i = b * 256 + threadIdx.x; i < n4; i += stride) {
+    size_t i = b * 256 + threadIdx.x;
+#if MMREC_ADAM_ILP >= 2
+    // two float4 per thread and trip: eight loads in flight before the first store (round 6 A/B: tools/prof_adam_dense.py)
+    for (; i + stride < n4; i += 2 * stride) {
+        const size_t j = i + stride;
+        float4 p0 = reinterpret_cast<float4*>(d.p)[i], p1 = reinterpret_cast<float4*>(d.p)[j];
+#if MMREC_ADAM_NT      // the gradient and the moments are touched once per step: streamed past the caches
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        auto ntl = [](const float* q, size_t k) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q) + k);
+                                                  return make_float4(t.x, t.y, t.z, t.w); };
+        const float4 g0 = ntl(d.g, i), g1 = ntl(d.g, j);
+        float4 m0 = ntl(d.m, i), m1 = ntl(d.m, j), v0 = ntl(d.v, i), v1 = ntl(d.v, j);
+#else
+        const float4 g0 = reinterpret_cast<const float4*>(d.g)[i], g1 = reinterpret_cast<const float4*>(d.g)[j];
+        float4 m0 = reinterpret_cast<float4*>(d.m)[i], m1 = reinterpret_cast<float4*>(d.m)[j];
+        float4 v0 = reinterpret_cast<float4*>(d.v)[i], v1 = reinterpret_cast<float4*>(d.v)[j];
+#endif
+        adam_one(p0.x, g0.x, m0.x, v0.x, a); adam_one(p0.y, g0.y, m0.y, v0.y, a);
+        adam_one(p0.z, g0.z, m0.z, v0.z, a); adam_one(p0.w, g0.w, m0.w, v0.w, a);
+        adam_one(p1.x, g1.x, m1.x, v1.x, a); adam_one(p1.y, g1.y, m1.y, v1.y, a);
+        adam_one(p1.z, g1.z, m1.z, v1.z, a); adam_one(p1.w, g1.w, m1.w, v1.w, a);
+#if MMREC_ADAM_NT
+        auto nts = [](float* q, size_t k, float4 x) { f4v t; t.x = x.x; t.y = x.y; t.z = x.z; t.w = x.w;
+                                                      __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(q) + k); };
+        reinterpret_cast<float4*>(d.p)[i] = p0; nts(d.m, i, m0); nts(d.v, i, v0);
+        reinterpret_cast<float4*>(d.p)[j] = p1; nts(d.m, j, m1); nts(d.v, j, v1);
+#else
+        reinterpret_cast<float4*>(d.p)[i] = p0; reinterpret_cast<float4*>(d.m)[i] = m0; reinterpret_cast<float4*>(d.v)[i] = v0;
+        reinterpret_cast<float4*>(d.p)[j] = p1; reinterpret_cast<float4*>(d.m)[j] = m1; reinterpret_cast<float4*>(d.v)[j] = v1;
+#endif
+    }
+#endif
+    for (; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4*>(d.p)[i];
         const float4 gg = reinterpret_cast<const float4*>(d.g)[i];
         float4 mm = reinterpret_cast<float4*>(d.m)[i], vv = reinterpret_cast<float4*>(d.v)[i];
