@@ -25,6 +25,10 @@ class GraphedTrainStep:
     def invalidate(self):
         """Call when buffers the step reads were re-created (new epoch / rebuilt graph)."""
         self.graph = None
+        # a plugin whose FIRST batch of an epoch does something the others do not (LATTICE builds its learned item graph
+        # there, lattice.py:137-159) declares `graph_eager_batches = 1`: those batches run eagerly, the capture is taken on
+        # the next one
+        self._eager_left = int(getattr(self.model, 'graph_eager_batches', 0) or 0)
 
     def _capture(self, batch):
         self.static_batch = batch.clone()
@@ -56,6 +60,9 @@ class GraphedTrainStep:
             self._warm = True
             return self._eager(batch)
         if self.failed:
+            return self._eager(batch)
+        if self.graph is None and getattr(self, '_eager_left', 0) > 0:
+            self._eager_left -= 1
             return self._eager(batch)
         if self.graph is None or batch.shape != self.static_batch.shape:
             if self.graph is not None and batch.shape != self.static_batch.shape:

@@ -30,7 +30,10 @@ def _sym_norm_values(rows, cols, vals, n):
 
 
 class LATTICE(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
-    graph_capturable = False   # the first batch of an epoch builds the item graph, later ones do not
+    # the first batch of an epoch builds the learned item graph (lattice.py:137-159), later ones reuse it: that batch runs
+    # eagerly, the step is captured on the second one and replayed for the rest of the epoch (common/graph_step.py)
+    graph_capturable = True
+    graph_eager_batches = 1
     relabelled_tables = {'user_embedding.weight': 'u', 'item_id_embedding.weight': 'i', 'image_embedding.weight': 'i',
                          'text_embedding.weight': 'i'}     # config key `reorder` (models/_base.py)
 

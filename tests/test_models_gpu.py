@@ -401,7 +401,10 @@ def test_device_negative_sampler(tmp_path, golden):
 
 @pytest.mark.parametrize("name,extra", [("LayerGCN", {"n_layers": 4, "reg_weight": 1e-3, "dropout": 0.1}),
                                         ("FREEDOM", {"dropout": 0.8, "reg_weight": 1e-3}),
-                                        ("MMGCN", {"reg_weight": 1e-3, "learning_rate": 1e-3})])
+                                        ("MMGCN", {"reg_weight": 1e-3, "learning_rate": 1e-3}),
+                                        # (LATTICE: the first batch of an epoch builds the item graph and runs eagerly,
+                                        #  the capture is taken on the second: small batches so that there are several)
+                                        ("LATTICE", {"reg_weight": 1e-3, "learning_rate": 1e-3, "train_batch_size": 64})])
 def test_graphed_train_step_equals_eager(tmp_path, golden, name, extra):
     """hip_graph_step: an epoch replayed as a hipGraph gives the same parameters as the eager epoch
     (same kernels in the same order; fp32 atomics in the BPR scatter allow last-ulp differences)."""
