@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 12
+#define MMREC_ABI_VERSION 13
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -478,6 +478,24 @@ int mmrec_adam_rows_step_dev_f32(float* p, float* m, float* v, const int64_t* id
                                  int32_t n_ids, int32_t F, int32_t* last_step, int32_t capacity, const int64_t* step_dev,
                                  const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
                                  int32_t presummed, mmrec_stream_t stream);
+/* ABI 13 -- OPT-IN fast-forward (config key `lazy_adam_fast_forward`, default off): the arguments and the bookkeeping of
+ * catchup / catchup_dev, but a row skipped for more than 12 steps is brought to step t_now in CLOSED FORM instead of being
+ * replayed step by step: m *= b1^n, v *= b2^n, p -= m0 * sum_j w_j / (sqrt(v0) d_j + eps) with the sum evaluated as a
+ * six-term series around the row's weighted-mean d (csrc/adam.hip; the row scalars W, dbar, M_2..M_6 come from `hist`).
+ * ~16 instructions per element whatever the gap (the exact replay: 7 per element AND skipped step).  NOT bit-identical to
+ * dense Adam: p within 2e-6 of the distance it moved, m / v within 1e-6 sqrt(n) relative (tests) -- inside north_star's
+ * 1e-4 tolerance, outside the "lazy == dense bit for bit" property, hence opt-in.  What the series does not serve to 1e-7
+ * (steps before optimizer step 128, where the bias correction of v moves by per cents per step: such a row is replayed to
+ * step 128 and advanced in closed form from there; b1^256 > 1e-9; weight decay; short gaps) takes the exact replay inside
+ * the same launch.
+ * replaces: the same torch.optim.Adam.step as above (trainer.py:111-128,189). */
+int mmrec_adam_rows_fastforward_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, int32_t n_ids,
+                                    int32_t n_rows, int32_t F, int32_t* last_step, const float* hist, int32_t t_now,
+                                    float beta1, float beta2, float eps, float weight_decay, mmrec_stream_t stream);
+int mmrec_adam_rows_fastforward_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner, int32_t n_ids,
+                                        int32_t n_rows, int32_t F, int32_t* last_step, const float* hist,
+                                        int32_t capacity, const int64_t* step_dev, float beta1, float beta2, float eps,
+                                        float weight_decay, mmrec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MMREC_HIP_LIB: load another build of the same library (kernel A/B measurements: tools/prof_topk_filter.py)
 LIB_PATH = os.environ.get("MMREC_HIP_LIB") or os.path.join(_PKG, "lib", "libmmrec_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _P = c_void_p  # every device/host pointer travels as void*
 
@@ -96,6 +96,10 @@ SIGNATURES = {
                                                   c_float, c_float, c_float, _P]),
     "mmrec_adam_rows_step_dev_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, c_float, c_float,
                                                c_float, c_float, c_int32, _P]),
+    "mmrec_adam_rows_fastforward_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, c_float,
+                                                  c_float, c_float, c_float, _P]),
+    "mmrec_adam_rows_fastforward_dev_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, _P,
+                                                      c_float, c_float, c_float, c_float, _P]),
 }
 
 _lib = None

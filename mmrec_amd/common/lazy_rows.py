@@ -12,6 +12,8 @@ state_dict) whose rows are brought up to date on demand and updated only where t
 
 The result equals dense Adam bit for bit (tests/test_hip_parity.py::test_lazy_row_adam_equals_dense).  `flush()`
 replays everything that is still postponed (before the table is read as a whole: state_dict, export).
+Opt-in `fast_forward` (config `lazy_adam_fast_forward: True`): rows skipped for long are advanced in closed form
+(`mmrec_adam_rows_fastforward_f32`) -- 1e-6-close to the replay, not bit-identical; off by default.
 No host synchronisation anywhere: duplicates are resolved by an `owner` array on the device, not by sort / unique.
 Under a capturable HipAdam (hipGraph replay of the training step, common/graph_step.py) nothing step-dependent comes from
 the host either: the step count and the two bias-correction scalars are read from the optimizer's device counters
@@ -89,6 +91,7 @@ class LazyRowEmbedding(nn.Embedding):
         self._overflow = None                   # device flag: a step beyond the capacity of `_hist` (checked per epoch)
         self._prefetched = None                 # (ids, event) of a catch-up running on the side stream
         self.allow_missing = False              # True: rows(ids) accepts -1 = "no row" (item-sharded tables: slots of other ranks)
+        self.fast_forward = False               # True (config lazy_adam_fast_forward): skipped steps in closed form, NOT bit-identical
 
     # ---- device state, created on first use (the module may have been moved since construction)
     def _state(self):
@@ -153,13 +156,16 @@ class LazyRowEmbedding(nn.Embedding):
         n = 0 if ids is None else ids.numel()
         if ids is not None:
             _lib.check(lib.mmrec_adam_rows_owner(_p(ids), n, _p(self._owner), _stream()), "adam_rows_owner")
+        fast = getattr(self, 'fast_forward', False)
         if self._dev is not None:
-            _lib.check(lib.mmrec_adam_rows_catchup_dev_f32(
+            fn = lib.mmrec_adam_rows_fastforward_dev_f32 if fast else lib.mmrec_adam_rows_catchup_dev_f32
+            _lib.check(fn(
                 _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
                 w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._hist.shape[0], _p(self._dev[0]), b1, b2,
                 eps, wd, _stream()), "adam_rows_catchup_dev")
             return
-        _lib.check(lib.mmrec_adam_rows_catchup_f32(
+        fn = lib.mmrec_adam_rows_fastforward_f32 if fast else lib.mmrec_adam_rows_catchup_f32
+        _lib.check(fn(
             _p(w), _p(m), _p(v), None if ids is None else _p(ids), None if ids is None else _p(self._owner), n,
             w.shape[0], w.shape[1], _p(self._last_step), _p(self._hist), self._t, b1, b2, eps, wd, _stream()),
             "adam_rows_catchup")       # (the kernel hands the owner marks back: all INT_MAX again)

@@ -100,6 +100,14 @@ class Trainer(AbstractTrainer):
         on_gpu = all(p.is_cuda for p in self.model.parameters())
         if name == 'adam' and on_gpu and (fused is None or fused):
             from mmrec_amd.common.optim import HipAdam   # one fused HIP kernel per tensor, same update rule
+            if self.config['lazy_adam_fast_forward']:      # opt-in, NOT bit-identical (common/lazy_rows.py)
+                from mmrec_amd.common.lazy_rows import LazyRowEmbedding
+                n_fast = 0
+                for mod in self.model.modules():
+                    if isinstance(mod, LazyRowEmbedding):
+                        mod.fast_forward, n_fast = True, n_fast + 1
+                self.logger.info('lazy_adam_fast_forward: %d row-lazy table(s) advance skipped steps in closed form '
+                                 '(1e-6-close to dense Adam, not bit-identical)' % n_fast)
             return HipAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,
                            capturable=self._graph_wanted())
         if any(getattr(p, '_lazy_table', None) is not None for p in self.model.parameters()):

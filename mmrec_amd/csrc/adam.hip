@@ -269,9 +269,85 @@ __device__ __forceinline__ bool adam_param_settled(float p, float m, float v, fl
     return bound < quarter_ulp;
 }
 
+// ---- OPT-IN fast-forward of a skipped row (config `lazy_adam_fast_forward`; NOT bit-identical to the dense kernel) ----
+// In real arithmetic a row skipped from step s0 to s0 + n has m_n = b1^n m0, v_n = b2^n v0 and
+//     p_n = p0 - m0 * sum_j w_j / (sqrt(v0) d_j + eps),   w_j = (lr_j / (1 - b1^(s0+j))) b1^j,   d_j = b2^(j/2) / sqrt(1 - b2^(s0+j))
+// (j = 1 .. n).  w_j and d_j belong to the ROW (they depend on s0 and j only), and d_j hardly varies over the ~100 steps whose
+// weight b1^j matters: with dbar = the w-weighted mean of d_j, delta_j = d_j / dbar - 1, y = sqrt(v0), A = y dbar + eps and
+// u = y dbar / A (0 <= u <= 1),
+//     sum_j w_j / (y d_j + eps) = (1 / A) sum_k (-u)^k M_k,        M_k = sum_j w_j delta_j^k   (M_0 = W, M_1 = 0)
+// for EVERY ratio of eps to sqrt(v) -- a geometric series in u delta_j, cut after k = 6 with a relative remainder
+// <= R = sum_j |w_j| |delta_j|^7 / |W| (tests/test_host_logic.py restates this in float64 against the direct sum).  The row's
+// workgroup forms W, dbar, M_2 .. M_6 and R once from the per-step scalar table (one step per thread: the first 256 skipped
+// steps; what follows weighs < b1^256), and every element then costs ~16 instructions whatever the gap.  The row is replayed
+// EXACTLY instead when R > 1e-7 (the first ~100 optimizer steps, where the bias correction of v still moves by per cents per
+// step: a row last visited then is replayed up to step FAST_FROM_STEP and advanced in closed form from there), when b1^256 >
+// 1e-9, under weight decay, or when the gap is short (<= FAST_MIN_GAP steps: the replay is as cheap).
+// Against the exact replay: p within 2e-6 of the distance it moved + half an ulp, m and v within 1e-6 sqrt(n) (the replay
+// rounds them n times; the closed form once) -- inside north_star's 1e-4, outside "lazy == dense bit for bit".
+constexpr int FAST_MIN_GAP = 12;
+constexpr int FAST_FROM_STEP = 128;
+struct FastRow {
+    float W, dbar, M2, M3, M4, M5, M6, B1, B2;
+    int ok;
+};
+
+__device__ __forceinline__ float block256_sum(float x, float* s_red /* [4] */) {
+    x = wave_sum(x);
+    __syncthreads();                                    // s_red free again
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__device__ __forceinline__ void adam_fast_row_scalars(FastRow& fr, const float2* __restrict__ hist, int s0, int t_now,
+                                                      float beta1, float beta2, float* s_red) {
+    const int n = t_now - s0, jp = (int)threadIdx.x + 1;
+    const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
+    float w = 0.f, d = 0.f;
+    if (jp <= n) {
+        const float2 h = hist[s0 + jp];
+        w = h.x * exp2f((float)jp * l2b1);
+        d = h.y * exp2f(0.5f * (float)jp * l2b2);
+    }
+    const float W = block256_sum(w, s_red);
+    const float dbar = block256_sum(w * d, s_red) / W;
+    const float de = jp <= n ? d / dbar - 1.f : 0.f;
+    const float de2 = de * de, w2 = w * de2, w4 = w2 * de2;
+    fr.W = W, fr.dbar = dbar;
+    fr.M2 = block256_sum(w2, s_red);
+    fr.M3 = block256_sum(w2 * de, s_red);
+    fr.M4 = block256_sum(w4, s_red);
+    fr.M5 = block256_sum(w4 * de, s_red);
+    fr.M6 = block256_sum(w4 * de2, s_red);
+    const float R = block256_sum(fabsf(w4 * de2 * de), s_red);
+    __syncthreads();
+    if (threadIdx.x < 2) s_red[threadIdx.x] = (float)pow((double)(threadIdx.x ? beta2 : beta1), (double)n);   // two lanes, once per row
+    __syncthreads();
+    fr.B1 = s_red[0], fr.B2 = s_red[1];
+    const bool tail_ok = n <= 256 || exp2f(256.f * l2b1) < 1e-9f;
+    fr.ok = tail_ok && fabsf(W) > 0.f && dbar > 0.f && R <= 1e-7f * fabsf(W) && isfinite(W) && isfinite(dbar);
+}
+
+__device__ __forceinline__ void adam_fast_one(float& p, float& m, float& v, const FastRow& fr, float eps) {
+    const float y = __builtin_amdgcn_sqrtf(v) * fr.dbar;
+    const float r = __builtin_amdgcn_rcpf(y + eps);
+    const float u = y * r;
+    float s = fmaf(-u, fr.M6, fr.M5);
+    s = fmaf(-u, s, fr.M4);
+    s = fmaf(-u, s, fr.M3);
+    s = fmaf(-u, s, fr.M2);
+    s = fmaf(u * u, s, fr.W);
+    p = fmaf(-(m * r), s, p);
+    m *= fr.B1;
+    v *= fr.B2;
+}
+
 // ids == nullptr: every row (flush).  One workgroup per listed row.  The row stays in registers while the steps
 // are replayed (columns in tiles of 4096 floats: 4 float4 per thread); the per-step scalars come through LDS in
 // tiles of 256 steps (one global load per step and thread made the first version wait on memory 135 us per call).
+// FAST: the opt-in closed form above for rows it serves; everything else takes the exact replay below.
+template <bool FAST>
 __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
     float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const int64_t* __restrict__ ids,
     int* __restrict__ owner, int F, int* __restrict__ last_step, const float2* __restrict__ hist, int t_now,
@@ -295,6 +371,14 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
     float4* p4 = reinterpret_cast<float4*>(p + (size_t)row * F);
     float4* m4 = reinterpret_cast<float4*>(m + (size_t)row * F);
     float4* v4 = reinterpret_cast<float4*>(v + (size_t)row * F);
+    FastRow fr;
+    fr.ok = 0;
+    // a row last visited in the first FAST_FROM_STEP steps is replayed exactly up to that step and advanced in closed form from
+    // there (early in a run the series is refused: the bias correction of v moves too fast)
+    const int s_fast = max(s0, min(t_now, FAST_FROM_STEP));
+    if (FAST && weight_decay == 0.f && t_now - s_fast > FAST_MIN_GAP)
+        adam_fast_row_scalars(fr, hist, s_fast, t_now, beta1, beta2, s_lmax);
+    const int t_exact = (FAST && fr.ok) ? s_fast : t_now;      // the exact replay covers steps s0 + 1 .. t_exact
     for (int c0 = 0; c0 < f4; c0 += 1024) {
         float4 pp[4], mm[4], vv[4];
 #pragma unroll
@@ -313,10 +397,10 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
                         vv[u].x == 0.f && vv[u].y == 0.f && vv[u].z == 0.f && vv[u].w == 0.f;
         if (__syncthreads_and(untouched)) continue;
         const float v_fac = 0.99f * powf(beta2, 128.f);         // sqrt(v) after <= 256 more decays, from below
-        for (int jb = s0 + 1; jb <= t_now; jb += 256) {
+        for (int jb = s0 + 1; jb <= t_exact; jb += 256) {
             __syncthreads();
             float lx = 0.f;
-            if (jb + (int)threadIdx.x <= t_now) {
+            if (jb + (int)threadIdx.x <= t_exact) {
                 s_h[threadIdx.x] = hist[jb + threadIdx.x];
                 lx = fabsf(s_h[threadIdx.x].x);
             }
@@ -325,7 +409,7 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
             if ((threadIdx.x & 63) == 0) s_lmax[threadIdx.x >> 6] = lx;
             __syncthreads();
             const float l_max = fmaxf(fmaxf(s_lmax[0], s_lmax[1]), fmaxf(s_lmax[2], s_lmax[3]));   // largest step size of the tile
-            const int nj = min(256, t_now - jb + 1);
+            const int nj = min(256, t_exact - jb + 1);
             for (int j0 = 0; j0 < nj; j0 += 32) {              // 32 steps at a time: can p still move?  (per wave)
                 const int j1 = min(j0 + 32, nj);
                 bool settled = weight_decay == 0.f;
@@ -369,6 +453,15 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(
                         adam_one(pp[u].w, 0.f, mm[u].w, vv[u].w, a);
                     }
                 }
+            }
+        }
+        if (FAST && fr.ok) {                                    // (uniform over the workgroup) steps t_exact + 1 .. t_now
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                adam_fast_one(pp[u].x, mm[u].x, vv[u].x, fr, eps);
+                adam_fast_one(pp[u].y, mm[u].y, vv[u].y, fr, eps);
+                adam_fast_one(pp[u].z, mm[u].z, vv[u].z, fr, eps);
+                adam_fast_one(pp[u].w, mm[u].w, vv[u].w, fr, eps);
             }
         }
 #pragma unroll
@@ -456,17 +549,22 @@ extern "C" int mmrec_adam_rows_owner(const int64_t* ids, int32_t n, int32_t* own
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
-                                           int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
-                                           const float* hist, int32_t t_now, float beta1, float beta2, float eps,
-                                           float weight_decay, mmrec_stream_t stream) {
+static int rows_catchup(bool fast, float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
+                        int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
+                        const float* hist, int32_t t_now, float beta1, float beta2, float eps,
+                        float weight_decay, mmrec_stream_t stream) {
     if (F <= 0 || (F & 3) || t_now < 0 || !p || !m || !v || !last_step || !hist) return MMREC_ERR_BAD_ARG;
     if (ids && !owner) return MMREC_ERR_BAD_ARG;
     const int blocks = ids ? n_ids : n_rows;
     if (blocks <= 0) return blocks < 0 ? MMREC_ERR_BAD_ARG : 0;
-    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner, F,
-                       last_step, reinterpret_cast<const float2*>(hist), t_now, beta1, beta2, eps, weight_decay,
-                       (const long long*)nullptr, 0);
+    if (fast)
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<true>, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner,
+                           F, last_step, reinterpret_cast<const float2*>(hist), t_now, beta1, beta2, eps, weight_decay,
+                           (const long long*)nullptr, 0);
+    else
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<false>, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids,
+                           owner, F, last_step, reinterpret_cast<const float2*>(hist), t_now, beta1, beta2, eps, weight_decay,
+                           (const long long*)nullptr, 0);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
@@ -478,18 +576,52 @@ extern "C" int mmrec_adam_hist_set_dev(float* hist, int32_t capacity, const int6
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int mmrec_adam_rows_catchup_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
-                                               int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
-                                               const float* hist, int32_t capacity, const int64_t* step_dev, float beta1,
-                                               float beta2, float eps, float weight_decay, mmrec_stream_t stream) {
+static int rows_catchup_dev(bool fast, float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
+                            int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
+                            const float* hist, int32_t capacity, const int64_t* step_dev, float beta1,
+                            float beta2, float eps, float weight_decay, mmrec_stream_t stream) {
     if (F <= 0 || (F & 3) || !p || !m || !v || !last_step || !hist || !step_dev || capacity < 2) return MMREC_ERR_BAD_ARG;
     if (ids && !owner) return MMREC_ERR_BAD_ARG;
     const int blocks = ids ? n_ids : n_rows;
     if (blocks <= 0) return blocks < 0 ? MMREC_ERR_BAD_ARG : 0;
-    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner, F,
-                       last_step, reinterpret_cast<const float2*>(hist), 0, beta1, beta2, eps, weight_decay,
-                       reinterpret_cast<const long long*>(step_dev), capacity);
+    if (fast)
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<true>, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids, owner,
+                           F, last_step, reinterpret_cast<const float2*>(hist), 0, beta1, beta2, eps, weight_decay,
+                           reinterpret_cast<const long long*>(step_dev), capacity);
+    else
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<false>, dim3(blocks), dim3(256), 0, mmrec_stream(stream), p, m, v, ids,
+                           owner, F, last_step, reinterpret_cast<const float2*>(hist), 0, beta1, beta2, eps, weight_decay,
+                           reinterpret_cast<const long long*>(step_dev), capacity);
     MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_adam_rows_catchup_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
+                                           int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
+                                           const float* hist, int32_t t_now, float beta1, float beta2, float eps,
+                                           float weight_decay, mmrec_stream_t stream) {
+    return rows_catchup(false, p, m, v, ids, owner, n_ids, n_rows, F, last_step, hist, t_now, beta1, beta2, eps, weight_decay,
+                        stream);
+}
+extern "C" int mmrec_adam_rows_fastforward_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
+                                               int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
+                                               const float* hist, int32_t t_now, float beta1, float beta2, float eps,
+                                               float weight_decay, mmrec_stream_t stream) {
+    return rows_catchup(true, p, m, v, ids, owner, n_ids, n_rows, F, last_step, hist, t_now, beta1, beta2, eps, weight_decay,
+                        stream);
+}
+extern "C" int mmrec_adam_rows_catchup_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
+                                               int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
+                                               const float* hist, int32_t capacity, const int64_t* step_dev, float beta1,
+                                               float beta2, float eps, float weight_decay, mmrec_stream_t stream) {
+    return rows_catchup_dev(false, p, m, v, ids, owner, n_ids, n_rows, F, last_step, hist, capacity, step_dev, beta1, beta2,
+                            eps, weight_decay, stream);
+}
+extern "C" int mmrec_adam_rows_fastforward_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,
+                                                   int32_t n_ids, int32_t n_rows, int32_t F, int32_t* last_step,
+                                                   const float* hist, int32_t capacity, const int64_t* step_dev, float beta1,
+                                                   float beta2, float eps, float weight_decay, mmrec_stream_t stream) {
+    return rows_catchup_dev(true, p, m, v, ids, owner, n_ids, n_rows, F, last_step, hist, capacity, step_dev, beta1, beta2,
+                            eps, weight_decay, stream);
 }
 
 extern "C" int mmrec_adam_rows_step_dev_f32(float* p, float* m, float* v, const int64_t* ids, int32_t* owner,

@@ -1975,6 +1975,154 @@ def test_lazy_row_adam_long_gaps_equal_dense_bitwise(dev):
         assert torch.equal(opt_l.state[lazy.weight][key], opt_d.state[dense.weight][key])
 
 
+def test_lazy_row_adam_fast_forward_one_call_against_the_exact_replay(dev):
+    """ABI 13, opt-in: mmrec_adam_rows_fastforward_f32 against mmrec_adam_rows_catchup_f32 on copies of the same state --
+    rows last visited at step s0, brought to step t_now; second moments over 20 decades (eps far above / near / far below
+    sqrt(v)), first moments of either sign and exact zeros, parameters that are zero / tiny / ordinary, gaps 1 ... 3000.
+    p within 2e-6 of the distance the replay moved it (+ the roundings the replay itself makes: half an ulp per step it
+    really moved), m and v within 1e-6 sqrt(gap) relative.  Rows the series does not serve (short gaps; a row that is still
+    inside the first 128 optimizer steps) come out BIT-identical: they took the exact replay inside the same launch; a row
+    last visited before step 128 is replayed to there and advanced in closed form for the rest."""
+    from mmrec_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    b1, b2, eps, lr, F = 0.9, 0.999, 1e-8, 1e-3, 4104
+    T = 6000
+    tt = np.arange(T, dtype=np.float64)
+    tt[0] = 1
+    hist = torch.tensor(np.stack([lr / (1 - b1 ** tt), 1 / np.sqrt(1 - b2 ** tt)], 1), dtype=torch.float32).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    cases = [(0, 40), (5, 200), (40, 13), (150, 1), (150, 12), (150, 13), (150, 60), (400, 122), (683, 500), (1000, 257),
+             (2500, 3000), (5000, 999)]
+    n = len(cases)
+    p0 = torch.randn(n, F, generator=gen) * 0.1
+    p0[:, ::9] = 0.0
+    p0[:, 1::9] *= 1e-5
+    v0 = 10.0 ** (torch.rand(n, F, generator=gen) * 20 - 20)
+    m0 = v0.sqrt() * torch.randn(n, F, generator=gen) * 3
+    m0[:, 2::9] = 0.0
+    last = torch.tensor([c[0] for c in cases], dtype=torch.int32)
+    out = {}
+    for fast in (False, True):
+        fn = lib.mmrec_adam_rows_fastforward_f32 if fast else lib.mmrec_adam_rows_catchup_f32
+        res = []
+        for r, (s0, gap) in enumerate(cases):            # one call per row: each row has its own t_now
+            p, m, v = p0.clone().to(dev), m0.clone().to(dev), v0.clone().to(dev)
+            ls = last.clone().to(dev)
+            ids = torch.tensor([r], dtype=torch.int64, device=dev)
+            owner = torch.full((n,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+            _lib.check(lib.mmrec_adam_rows_owner(P(ids), 1, P(owner), None), "owner")
+            _lib.check(fn(P(p), P(m), P(v), P(ids), P(owner), 1, n, F, P(ls), P(hist), s0 + gap, b1, b2, eps, 0.0, None),
+                       "catchup")
+            torch.cuda.synchronize()
+            assert int(ls[r]) == s0 + gap and int(owner[r]) == 2 ** 31 - 1
+            others = torch.arange(n) != r
+            assert torch.equal(p.cpu()[others], p0[others])                       # only the listed row moved
+            res.append((p[r].cpu().double(), m[r].cpu().double(), v[r].cpu().double()))
+        out[fast] = res
+    def remainder(s0, gap):                              # adam_fast_row_scalars' R in float64 (tests/test_host_logic.py)
+        jp = np.arange(1, min(gap, 256) + 1, dtype=np.float64)
+        w = hist[s0 + 1:s0 + 1 + jp.size, 0].cpu().double().numpy() * b1 ** jp
+        d = hist[s0 + 1:s0 + 1 + jp.size, 1].cpu().double().numpy() * b2 ** (jp / 2)
+        de = d / ((w * d).sum() / w.sum()) - 1
+        return (np.abs(w) * np.abs(de) ** 7).sum() / w.sum()
+
+    worst = 0.0
+    for r, (s0, gap) in enumerate(cases):
+        (pe, me, ve), (pf, mf, vf) = out[False][r], out[True][r]
+        s_f = max(s0, min(s0 + gap, 128))                # adam.hip FAST_FROM_STEP: exact replay up to step 128, closed form from there
+        R = remainder(s_f, s0 + gap - s_f) if s0 + gap - s_f > 12 else 1.0
+        if s0 + gap - s_f <= 12 or R > 2e-7:
+            assert torch.equal(pe, pf) and torch.equal(me, mf) and torch.equal(ve, vf), (s0, gap)   # exact replay inside
+            continue
+        moved = (pe - p0[r].double()).abs()
+        ulp = torch.maximum(pe.abs(), p0[r].double().abs()) * 2.0 ** -24
+        tol = 2e-6 * moved + ulp * min(gap, 150) * 0.5 + 1e-12
+        rel = ((pf - pe).abs() / tol).max().item()
+        errs = [((a - b).abs()[a.abs() > 1e-30] / a.abs()[a.abs() > 1e-30]).max().item() if bool((a.abs() > 1e-30).any()) else 0.0
+                for a, b in ((me, mf), (ve, vf))]          # (below 1e-30 the replay's denormals and the closed form's zero differ)
+        print("s0 %d gap %d R %.1e: p error / tolerance %.3f (max |dp| %.2e of moved %.2e), m %.1e v %.1e%s" %
+              (s0, gap, R, rel, (pf - pe).abs().max().item(), moved.max().item(), errs[0], errs[1],
+               "  [bit-identical: exact replay]" if torch.equal(pe, pf) else ""))
+        if R > 5e-8 and torch.equal(pe, pf):
+            continue                                     # (R within rounding of the kernel's 1e-7 line: either path)
+        worst = max(worst, rel)
+        assert rel <= 1.0, (s0, gap, rel)
+        for a, b, err in ((me, mf, errs[0]), (ve, vf, errs[1])):
+            assert err <= 1e-6 * gap ** 0.5 + 2e-7, (s0, gap, err)
+            assert float((a - b).abs().max()) <= 1e-30 or err > 0
+            assert bool((b[a == 0] == 0).all())
+        assert not torch.equal(pe, pf)                   # (the closed form really ran)
+    print("fast-forward, one call: worst error / tolerance %.3f" % worst)
+
+
+def test_lazy_row_adam_fast_forward_training_run_close_to_dense(dev):
+    """the opt-in fast-forward through LazyRowEmbedding + HipAdam (fast_forward = True) over 900 steps with rows that sit out
+    1 ... 699 steps, gradient columns of size 1, 1e-3 and 1e-6 (sqrt(v) from far above eps to below it) and a
+    learning-rate schedule, judged against torch.optim.Adam's recurrence in FLOAT64: the fast-forwarded table is as close to
+    it as the dense fp32 kernel is (largest error <= 1.5 x the dense kernel's, element by element <= 1e-5 of the distance
+    moved + 3 x the dense kernel's largest error; the fp32 kernels round p every step, ~5e-7 after 900 steps of a
+    parameter of size 1) -- and the two fp32 tables differ by no more than that from each other.  The default table
+    (fast_forward False) in the same run stays bit-identical to the dense kernel."""
+    from mmrec_amd.common.lazy_rows import LazyRowEmbedding
+    from mmrec_amd.common.optim import HipAdam
+    n, F, T, lr0, b1, b2, eps = 56, 260, 900, 1e-3, 0.9, 0.999, 1e-8
+    g = torch.Generator().manual_seed(12)
+    w0 = torch.randn(n, F, generator=g) * 0.3
+    w0[:, ::7] = 0.0
+    scale = torch.tensor([1.0, 1e-3, 1e-6])[torch.arange(F) % 3].to(dev)
+    gaps = torch.tensor([1, 7, 13, 60, 150, 333, 699])[torch.arange(n) % 7]
+    dense = torch.nn.Embedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    exact = LazyRowEmbedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    fast = LazyRowEmbedding.from_pretrained(w0.clone(), freeze=False).to(dev)
+    fast.fast_forward = True
+    opts = [HipAdam([t.weight], lr=lr0) for t in (dense, exact, fast)]
+    schs = [torch.optim.lr_scheduler.LambdaLR(o, lr_lambda=lambda ep: 0.9 ** ep) for o in opts]
+    p64 = w0.double().to(dev)
+    m64, v64 = torch.zeros_like(p64), torch.zeros_like(p64)
+    lr = lr0
+    for step in range(T):
+        ids = torch.nonzero(step % gaps == 0).flatten()
+        coef = (torch.randint(-16, 17, (ids.numel(), F), generator=g).float() / 16).to(dev) * scale
+        ids = ids.to(dev)
+        rows = [dense.weight[ids], exact.rows(ids), fast.rows(ids)]
+        assert torch.equal(rows[0], rows[1]), step
+        for o, r in zip(opts, rows):
+            o.zero_grad()
+            (r * coef).sum().backward()
+            o.step()
+        g64 = torch.zeros_like(p64).index_add_(0, ids, coef.double())
+        m64 = b1 * m64 + (1 - b1) * g64
+        v64 = b2 * v64 + (1 - b2) * g64 * g64
+        t = step + 1
+        p64 = p64 - (lr / (1 - b1 ** t)) * m64 / (v64.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
+        if step % 200 == 199:
+            for sc in schs:
+                sc.step()
+            lr = lr0 * 0.9 ** ((step + 1) // 200)
+    exact.flush(), fast.flush()
+    assert torch.equal(exact.weight, dense.weight)
+    e_dense, e_fast = (dense.weight.double() - p64).abs(), (fast.weight.double() - p64).abs()
+    moved = (p64 - w0.double().to(dev)).abs()
+    print("900 steps: largest error against float64 Adam: dense fp32 kernel %.2e, fast-forwarded table %.2e (largest move %.2e); "
+          "fast against dense %.2e" % (e_dense.max().item(), e_fast.max().item(), moved.max().item(),
+                                       (fast.weight - dense.weight).abs().max().item()))
+    for gp in (1, 7, 13, 60, 150, 333, 699):
+        sel = (gaps == gp).to(dev)
+        print("  rows touched every %3d steps: dense %.2e  fast %.2e" % (gp, e_dense[sel].max().item(), e_fast[sel].max().item()))
+    assert e_fast.max().item() <= 1.5 * e_dense.max().item()
+    assert bool((e_fast <= 1e-5 * moved + 3 * e_dense.max()).all())
+    assert (fast.weight - dense.weight).abs().max().item() <= 2.5 * e_dense.max().item()
+    assert not torch.equal(fast.weight, dense.weight)
+    for key, ref in (("exp_avg", m64), ("exp_avg_sq", v64)):
+        a, bb = opts[0].state[dense.weight][key].double(), opts[2].state[fast.weight][key].double()
+        big = ref.abs() > 1e-30
+        ea, eb = ((a - ref).abs() / ref.abs())[big].max().item(), ((bb - ref).abs() / ref.abs())[big].max().item()
+        print("  %s: largest relative error against float64: dense %.2e  fast %.2e" % (key, ea, eb))
+        assert eb <= max(1.5 * ea, 2e-6), key
+
+
 def test_lazy_row_adam_under_graph_replay_equals_dense(dev):
     """Round-1 review item 8: the row-lazy Adam inside a REPLAYED hipGraph step.  The step-dependent scalars come from the
     capturable HipAdam's device counters (mmrec_adam_*_dev entry points), the per-step table is reserved per capture.
@@ -2006,8 +2154,10 @@ def test_lazy_row_adam_under_graph_replay_equals_dense(dev):
             rows = self.table.rows(ids) if self.lazy else self.table.weight[ids]
             return (rows * coefs[ids]).sum() + (self.lin ** 2).sum()
 
-    def run(lazy):
+    def run(lazy, fast=False):
         net = Net(lazy).to(dev)
+        if fast:
+            net.table.fast_forward = True
         opt = HipAdam(net.parameters(), lr=1e-2, capturable=True)
         step = GraphedTrainStep(net, opt)
         for e, batches in enumerate(epochs):
@@ -2028,6 +2178,12 @@ def test_lazy_row_adam_under_graph_replay_equals_dense(dev):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert not torch.equal(a[0].cpu(), w0)
+    # ABI 13: the opt-in fast-forward inside the replayed step (mmrec_adam_rows_fastforward_dev_f32: step count from the device)
+    c = run(True, fast=True)
+    moved = (b[0] - w0.to(dev)).abs()
+    assert not torch.equal(c[0], b[0])
+    assert bool(((c[0] - b[0]).abs() <= 1e-5 * moved + 4e-6).all()), ((c[0] - b[0]).abs().max().item(), moved.max().item())
+    assert torch.allclose(c[2], b[2], rtol=1e-4, atol=1e-30) and torch.equal(c[3], b[3])
 
 
 def test_lazy_row_adam_long_id_lists_under_capture(dev):

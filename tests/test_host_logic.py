@@ -425,6 +425,54 @@ def test_lazy_adam_settled_parameter_bound_holds():
     assert (first >= 0).mean() > 0.85 and np.median(first[first >= 0]) <= 320
 
 
+def _adam_skipped_updates_direct(s0, n, lr, b1, b2, eps, m0, v0):
+    """sum of the n updates dense Adam applies to a parameter whose gradient is zero from step s0 + 1 on (float64)"""
+    jp = np.arange(1, n + 1, dtype=np.float64)[:, None]
+    t = s0 + jp
+    return ((lr / (1 - b1 ** t)) * b1 ** jp * m0[None] / (np.sqrt(v0[None] * b2 ** jp) / np.sqrt(1 - b2 ** t) + eps)).sum(0)
+
+
+def _adam_skipped_updates_series(s0, n, lr, b1, b2, eps, m0, v0, K=6, J=256):
+    """csrc/adam.hip: adam_fast_row_scalars + adam_fast_one in float64 (the opt-in fast-forward of a skipped row)"""
+    jp = np.arange(1, min(n, J) + 1, dtype=np.float64)
+    t = s0 + jp
+    w = (lr / (1 - b1 ** t)) * b1 ** jp
+    d = b2 ** (jp / 2) / np.sqrt(1 - b2 ** t)
+    W = w.sum()
+    dbar = (w * d).sum() / W
+    de = d / dbar - 1
+    M = [(w * de ** k).sum() for k in range(K + 1)]
+    R = (np.abs(w) * np.abs(de) ** (K + 1)).sum() / abs(W)
+    y = np.sqrt(v0) * dbar
+    r = 1 / (y + eps)
+    u = y * r
+    s = M[K]
+    for k in range(K - 1, 1, -1):
+        s = M[k] - u * s
+    return m0 * r * (W + u * u * s), R
+
+
+def test_lazy_adam_fast_forward_series_equals_the_direct_sum():
+    """The opt-in closed form of the row-lazy catch-up (include/mmrec_hip.h: mmrec_adam_rows_fastforward_f32): the sum of a
+    skipped row's updates as a six-term series around the row's weighted-mean d.  For second moments over 22 decades (eps
+    far above, near and far below sqrt(v)) the series is within 2 R of the direct sum, R being the remainder estimate the
+    kernel forms; R <= 1e-7 -- the kernel's condition for using it -- holds from ~100 optimizer steps on for ANY gap, and is
+    refused (exact replay) in the first steps, where the bias correction of v moves by per cents per step."""
+    rng = np.random.default_rng(0)
+    for s0 in (0, 3, 10, 30, 50, 100, 300, 683, 5000):
+        for n in (13, 17, 122, 500, 3000):
+            v0 = 10.0 ** rng.uniform(-22, 0, 1000)
+            m0 = np.sqrt(v0) * rng.normal(size=1000) * 3
+            direct = _adam_skipped_updates_direct(s0, n, 1e-3, 0.9, 0.999, 1e-8, m0, v0)
+            series, R = _adam_skipped_updates_series(s0, n, 1e-3, 0.9, 0.999, 1e-8, m0, v0)
+            err = np.max(np.abs(series - direct) / np.abs(direct))
+            assert err <= 2 * R + 1e-11, (s0, n, R, err)
+            if s0 >= 100:
+                assert R <= 1e-7 and err <= 2e-7, (s0, n, R)
+            if s0 <= 10 and n >= 100:
+                assert R > 1e-7, (s0, n, R)            # refused: the kernel replays these rows exactly
+
+
 @pytest.mark.parametrize("kd", [192, 384, 4096])
 def test_wide_rows_error_bound_holds(kd):
     """The margin the wide-row path (csrc/topk_wide.h: kd = 192 ... 4096) tests its 64 approximate candidates with, restated in

@@ -294,6 +294,47 @@ def test_freedom_lazy_feature_adam_equals_dense(tmp_path, golden):
     # items and 128+ samples per batch nearly every item here is such a duplicate)
 
 
+def test_freedom_lazy_adam_fast_forward_is_opt_in_and_close(tmp_path, golden):
+    """config `lazy_adam_fast_forward` (ABI 13, default OFF): the Trainer marks the model's row-lazy tables, rows that sat out
+    more than 12 steps are advanced in closed form, and 90 optimizer steps on small batches (each touches <= 12 of the 90
+    items, so rows sit out 5 ... 40 steps) end within 1e-4 / 2e-6 of the exact row-lazy run -- the tolerance of
+    test_freedom_lazy_feature_adam_equals_dense -- with feature tables that are NOT bit-identical (the closed form ran);
+    without the key the tables are not marked."""
+    if not USE_GPU:
+        pytest.skip("the row-lazy Adam is HIP kernels end to end (no CPU stand-in)")
+    from mmrec_amd.common.lazy_rows import LazyRowEmbedding, flush_lazy_tables
+    from mmrec_amd.common.trainer import Trainer
+    g = golden
+    finals = []
+    for fast in (False, True):
+        extra = {"dropout": 0.8, "reg_weight": 1e-3, "lazy_feature_adam": True, "learning_rate": 1e-3,
+                 "hip_graph_step": False}
+        if fast:
+            extra["lazy_adam_fast_forward"] = True
+        config, train_data, _, model = build(tmp_path, g, "FREEDOM", extra)
+        for k, v in extra.items():
+            config[k] = v
+        assert isinstance(model.image_embedding, LazyRowEmbedding)
+        for name, key in (("user_embedding.weight", "fr_user_emb"), ("item_id_embedding.weight", "fr_item_emb"),
+                          ("image_trs.weight", "fr_image_W"), ("text_trs.weight", "fr_text_W")):
+            load(dict(model.named_parameters())[name], g[key])
+        trainer = Trainer(config, model)
+        assert model.image_embedding.fast_forward is fast and model.text_embedding.fast_forward is fast
+        model.set_kept_edges(torch.as_tensor(g["fr_keep_idx"]).to(model.device))
+        model.train()
+        batch = torch.as_tensor(g["batch"][:3]).to(model.device)
+        for step in range(90):
+            b = torch.roll(batch, shifts=7 * step, dims=1)[:, :6]
+            trainer.optimizer.zero_grad()
+            model.calculate_loss(b).backward()
+            trainer.optimizer.step()
+        flush_lazy_tables(model)
+        finals.append({k: v.detach().clone() for k, v in model.named_parameters()})
+    for k in finals[0]:
+        np.testing.assert_allclose(finals[1][k].cpu().numpy(), finals[0][k].cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    assert not torch.equal(finals[0]["image_embedding.weight"], finals[1]["image_embedding.weight"])
+
+
 def test_lattice_model(tmp_path, golden):
     """LATTICE: sparse learned item graph (top-K kernel + differentiable values + spmm_vals) vs the
     reference's dense formulation: item graph, forward, loss and gradients on the graph-building batch

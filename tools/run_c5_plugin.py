@@ -53,6 +53,8 @@ def main():
             cd["hip_graph_step"] = False
         if os.environ.get("MMREC_C5_NO_PREFETCH"):
             cd["lazy_prefetch"] = False
+        if os.environ.get("MMREC_C5_FAST_FORWARD"):      # opt-in closed-form catch-up of the row-lazy tables (not bit-identical)
+            cd["lazy_adam_fast_forward"] = True
         config = Config("FREEDOM", "c5", cd)
         for k, v in cd.items():
             config[k] = v
