@@ -22,6 +22,9 @@
 #ifndef MMREC_GEMM_LEGACY_FWD
 #define MMREC_GEMM_LEGACY_FWD 0   // probe: force the register-staged forward for every F
 #endif
+#ifndef MMREC_FWD_ROT
+#define MMREC_FWD_ROT 11         // split-operand forward over an X streamed from HBM: row block b starts its k walk at tile (b * ROT) % T of its chunk (0 = every block at tile 0)
+#endif
 #ifndef MMREC_GEMM_DYN_LDS
 #define MMREC_GEMM_DYN_LDS 0   // probe: extra dynamic LDS per workgroup, caps workgroups per CU
 #endif
@@ -299,8 +302,21 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_dma_f16x3_kernel(const floa
         const int r = 16 * wave + 8 * j + (lane >> 3);
         vw[j] = r * F * 4 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
+    // Row blocks walk their k chunk from DIFFERENT starting tiles (and wrap): with every workgroup at the same column window of
+    // rows 16 KB apart the launch ran 10-13 % slower at one chunk per row block (Sports 92.7 -> 81 us, Clothing 90 -> 83 us
+    // forward, profiles/r06_linear_fwd_rotation_and_splits.log); a row's summation order then depends on its block, which the
+    // split count already made a function of n -- fp32-accurate either way (the tests' float64 comparisons).
+    // Only for an X that is streamed from HBM (NT: larger than the Infinity Cache): against a cache-resident X the rotation
+    // measured 1-2 us SLOWER (7,050 rows: 96.8 against 94.5 us forward + backward as a replay; 4,096 rows: +1.5 us).
+#if MMREC_FWD_ROT
+    const int rot = (NT && T > 0) ? (int)((blockIdx.x * (unsigned)MMREC_FWD_ROT) % (unsigned)T) : 0;
+#else
+    const int rot = 0;
+#endif
     auto issue = [&](float* xs, float* ws, int t) {
-        const int so = (kb + t * DM_BK) * 4;
+        int tt = t + rot;
+        if (tt >= T) tt -= T;
+        const int so = (kb + tt * DM_BK) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds_dma16<NT>(rx, lds_addr(xs + (4 * wave + j) * 256), vx[j], so);
 #pragma unroll
@@ -1210,7 +1226,12 @@ inline void pick_split(int tiles, int extent, int gran, int* nsplit, int* chunk)
 // and 8 item-splits of dW at every size (16): -7.6 % forward + backward at 4,096 rows, -2.7 % at 7,050, -3.5 % at 23,033.
 inline void pick_split_stream(int tiles, int extent, int gran, int* nsplit, int* chunk) {
     int s = 256 / tiles;                                   // at most one workgroup per CU ...
-    if (s < 2) s = tiles <= 200 ? 2 : 1;                   // ... but two chunks while a single one would leave a fifth of the chip idle
+    // ... and between 129 and 255 row blocks: a CU runs its workgroups at about the rate of one (the kernel is bound per CU:
+    // ~0.6 us per 128 x 32 tile whether one or two workgroups are resident), so the launch ends with the most loaded CU.  Two
+    // chunks per block put two half-length workgroups on tiles - 128 ... CUs: the same makespan as one chunk plus a slab pass;
+    // THREE chunks (<= 512 workgroups: all resident) cut it to 2/3 (Sports, 144 blocks: 95-97 us with two, 77-78 with three,
+    // 81-83 with one; Clothing, 180 blocks: 540 workgroups would not be resident together -- one chunk, 86-97 against 95-101).
+    if (s < 2) s = tiles <= 170 ? 3 : 1;
     const int max_s = ceil_div(extent, 2 * gran);          // a chunk is at least two tiles of the ring
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -1226,6 +1247,9 @@ extern "C" size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out
     pick_split(ceil_div(n, LIN_BM), F, LIN_BK, &s1, &c1);
     pick_split_stream(ceil_div(n, LIN_BM), F, LIN_BK, &s1s, &c1s);      // (the split-operand forward's rule)
     if (s1s > s1) s1 = s1s;
+#ifdef MMREC_FWD_SPLIT      // probe builds force the forward's split count: room for their slabs
+    if (s1 < MMREC_FWD_SPLIT + 1) s1 = MMREC_FWD_SPLIT + 1;
+#endif
     pick_split(ceil_div(F, BW_BF), n, BW_BK, &s2, &c2);
     // forward: partial slabs, then (mmrec_linear_fwd_split_f32) the 64 x F split copy of W, the per-slab row maxima of |X| and
     // the redo flags of its domain check (one per 128-row block + one per W row)

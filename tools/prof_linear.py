@@ -26,9 +26,11 @@ def timed(fn, reps):
 def main():
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(0)
-    for name, n, f in (("baby", 7050, 4096), ("sports", 18357, 4096), ("clothing", 23033, 4096),
-                       ("baby-text", 7050, 384), ("clothing-text", 23033, 384), ("vbpr-baby", 7050, 4480),
-                       ("c5-shard", 62500, 4096), ("c5", 500000, 4096)):
+    shapes = [("baby", 7050, 4096), ("sports", 18357, 4096), ("clothing", 23033, 4096),
+              ("baby-text", 7050, 384), ("clothing-text", 23033, 384), ("vbpr-baby", 7050, 4480),
+              ("c5-shard", 62500, 4096), ("c5", 500000, 4096)]
+    shapes += [(a, int(a[1:]), 4096) for a in sys.argv[1:] if a[0] == "n" and a[1:].isdigit()]     # n12000: 12,000 rows x 4096
+    for name, n, f in shapes:
         if sys.argv[1:] and name not in sys.argv[1:]:        # python tools/prof_linear.py baby c5 : only these shapes
             continue
         X = torch.rand(n, f, device=dev, generator=gen)
@@ -84,8 +86,9 @@ def run_variants(shapes):
     """python tools/prof_linear.py run-variants [shapes...]   (GPU): every variant library in its own process, twice"""
     import subprocess
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_libs")
+    names = os.environ["MMREC_VARIANTS"].split(",") if os.environ.get("MMREC_VARIANTS") else list(VARIANTS)   # (built by build-variants name=flags)
     for rnd in range(2):
-        for name in VARIANTS:
+        for name in names:
             env = dict(os.environ, MMREC_HIP_LIB=os.path.join(out, "libmmrec_bwd_%s.so" % name))
             r = subprocess.run([sys.executable, os.path.abspath(__file__)] + shapes, env=env, capture_output=True, text=True)
             for line in r.stdout.strip().splitlines():
