@@ -24,6 +24,20 @@ class HipAdam(torch.optim.Optimizer):
         self.capturable = capturable
         self.multi_tensor = multi_tensor   # one launch per parameter group (<= 24 tensors each) instead of one per tensor
         self._dev = {}   # id(group) -> (step int64[1], lr fp32[1], hyper fp32[2]) when capturable
+        # config `reorder` (models/_base.py: RelabelledIdsMixin): the per-row state of a relabelled table -- both moments -- lives in
+        # the table's row order.  The Trainer registers the tables' permutations here, and a checkpoint then holds that state in the
+        # DATASET's row order like the model's state_dict does (it loads under any `reorder`, or none); the tag is saved with it
+        # and checked where a table's rows could not be mapped (round-5 advice)
+        self._row_orders, self._row_order_tag, self._row_order_complete = {}, None, True
+
+    def set_row_order(self, orders, tag, complete=True):
+        """orders: {parameter: (perm, inv)} -- dataset row `old` lives at table row perm[old], table row `new` holds dataset row
+        inv[new]; tag: a string naming the relabelling (mode + checksum); complete: False when the model has id-indexed state
+        these maps do not cover (row-sharded feature tables): such a checkpoint only loads under the same tag."""
+        self._row_orders, self._row_order_tag, self._row_order_complete = dict(orders), tag, bool(complete)
+
+    def _indexed_params(self):
+        return [p for group in self.param_groups for p in group['params']]
 
     def _moments(self, p):
         st = self.state[p]
@@ -78,12 +92,35 @@ class HipAdam(torch.optim.Optimizer):
                     for p in group['params']:
                         if p in self.state and self.state[p]:
                             self.state[p]['step'] = n
-        return super().state_dict()
+        sd = super().state_dict()
+        if self._row_orders:
+            sd['state'] = dict(sd['state'])
+            for i, p in enumerate(self._indexed_params()):
+                if p in self._row_orders and i in sd['state']:
+                    perm = self._row_orders[p][0]
+                    sd['state'][i] = {k: (v.index_select(0, perm.to(v.device)) if torch.is_tensor(v) and v.dim() >= 1 and
+                                          v.shape[0] == p.shape[0] else v) for k, v in sd['state'][i].items()}
+        sd['mmrec_row_order'] = self._row_order_tag
+        return sd
 
     def load_state_dict(self, state_dict):
         """torch restores the moments and the host step counts; the DEVICE step counters of a capturable (hipGraph) optimizer
         and the row-lazy tables' bookkeeping are restored here, so that a resumed run continues with the bias corrections of
-        step n + 1 (and lazy rows are known to be current at step n: a checkpoint holds flushed tables)."""
+        step n + 1 (and lazy rows are known to be current at step n: a checkpoint holds flushed tables).  Per-row state of
+        relabelled tables (config `reorder`) arrives in the dataset's row order and is brought into this run's order."""
+        state_dict = dict(state_dict)
+        saved_tag = state_dict.pop('mmrec_row_order', None)
+        if saved_tag != self._row_order_tag and not self._row_order_complete:
+            raise ValueError('HipAdam.load_state_dict: the checkpoint was written under row order %r, this run uses %r, and the '
+                             'model keeps per-row optimizer state that cannot be re-ordered (row-sharded feature tables)'
+                             % (saved_tag, self._row_order_tag))
+        if self._row_orders:
+            state_dict['state'] = dict(state_dict['state'])
+            for i, p in enumerate(self._indexed_params()):
+                if p in self._row_orders and i in state_dict['state']:
+                    inv = self._row_orders[p][1]
+                    state_dict['state'][i] = {k: (v.index_select(0, inv.to(v.device)) if torch.is_tensor(v) and v.dim() >= 1 and
+                                                  v.shape[0] == p.shape[0] else v) for k, v in state_dict['state'][i].items()}
         super().load_state_dict(state_dict)
         for group in self.param_groups:
             n = 0

@@ -108,8 +108,15 @@ class Trainer(AbstractTrainer):
                         mod.fast_forward, n_fast = True, n_fast + 1
                 self.logger.info('lazy_adam_fast_forward: %d row-lazy table(s) advance skipped steps in closed form '
                                  '(1e-6-close to dense Adam, not bit-identical)' % n_fast)
-            return HipAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,
-                           capturable=self._graph_wanted())
+            opt = HipAdam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,
+                          capturable=self._graph_wanted())
+            rl = getattr(self.model, 'relabelling', None)
+            if rl is not None:       # config `reorder`: optimizer checkpoints hold per-row state in the dataset's row order
+                params = dict(self.model.named_parameters())
+                orders = {params[n]: ((rl.perm_u, rl.inv_u) if side == 'u' else (rl.perm_i, rl.inv_i))
+                          for n, side in self.model.relabelled_tables.items() if n in params}
+                opt.set_row_order(orders, rl.tag(), complete=not getattr(self.model, 'row_order_partial', False))
+            return opt
         if any(getattr(p, '_lazy_table', None) is not None for p in self.model.parameters()):
             raise ValueError('the model was built with row-lazy feature tables (lazy_feature_adam) but this Trainer '
                              'does not use the fused HIP Adam: set lazy_feature_adam: False')

@@ -103,6 +103,11 @@ class BipartiteRelabelling:
     def node_perm_host(self):
         return np.concatenate([self.perm_u_host, self.n_users + self.perm_i_host])
 
+    def tag(self):
+        """names this relabelling in checkpoints: the mode and a checksum of the two permutations"""
+        import zlib
+        return "%s:%08x" % (self.how, zlib.crc32(self.perm_i_host.tobytes(), zlib.crc32(self.perm_u_host.tobytes())))
+
     def to(self, device):
         for k in ("perm_u", "perm_i", "inv_u", "inv_i"):
             setattr(self, k, getattr(self, k).to(device))

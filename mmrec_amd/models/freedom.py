@@ -477,6 +477,11 @@ class RowShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
         users, mask = interaction[0], interaction[1]
         u, cands = self._cached_eval_candidates()          # the replicated item table, prepared once per evaluation
         i = cands.C if isinstance(cands, hip_ops.TopkCandidates) else cands
+        rl = self.relabelling                              # (SlicedFREEDOM under `reorder`; None otherwise)
+        if rl is not None:
+            users = rl.perm_u[users]
+            if mask.shape[1]:
+                mask = torch.stack([mask[0], rl.perm_i[mask[1]]])
         rowptr, cols = mask_to_csr_device(mask, users.shape[0], i.shape[0])
         b = users.shape[0]
         per = -(-b // self.world)
@@ -487,11 +492,11 @@ class RowShardedFREEDOM(FusedEvalMixin, GeneralRecommender):
             s, e = int(rp[0]), int(rp[-1])
             out[:hi - lo] = hip_ops.score_topk(u[users[lo:hi]].contiguous(), cands, k, (rp - rp[0]).contiguous(),
                                                cols[s:max(e, s + 1)].contiguous() if e > s else None)
-        if self.world == 1:
-            return out[:b]
-        full = torch.empty(self.world * per, k, dtype=torch.int64, device=users.device)
-        tdist.all_gather_into_tensor(full, out, group=self.group)
-        return full[:b]
+        if self.world > 1:
+            full = torch.empty(self.world * per, k, dtype=torch.int64, device=users.device)
+            tdist.all_gather_into_tensor(full, out, group=self.group)
+            out = full
+        return out[:b] if rl is None else rl.inv_i[out[:b]]      # ranked in the tables' id space, reported in the dataset's
 
     @torch.no_grad()
     def gather_feature_tables(self):
@@ -540,7 +545,7 @@ class _TakeColumns(torch.autograd.Function):
         return full, None, None, None, None
 
 
-class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
+class SlicedFREEDOM(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
     """FREEDOM over `n_gpus` = P in {2, 4, 8} processes, the FEATURE dimension sliced:
 
       * every rank holds the WHOLE user-item graph (and its per-epoch pruned version) and the whole item-item graph, and
@@ -554,7 +559,15 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
       * evaluation: the slices of the final tables are all-gathered ONCE per evaluation into replicated [N, 64] tables, then
         every rank ranks its share of the users (no exchange in the scoring).
     Parameter names are FREEDOM's; `user_embedding.weight` / `item_id_embedding.weight` hold the rank's columns,
-    `image_embedding.weight` / `text_embedding.weight` the rank's rows (`gather_tables()` rebuilds the full tensors)."""
+    `image_embedding.weight` / `text_embedding.weight` the rank's rows (`gather_tables()` rebuilds the full tensors).
+    Config key `reorder` (round 6: the layout where it pays most -- a gathered row of a d / P slice is a fraction of a 128-byte
+    line, and a relabelling that groups neighbours is worth 34 % per 8-column layer, bench.py extra.c5_grouped_ids): every
+    rank derives the SAME relabelling from the full graph, all id-indexed state -- the column slices' rows, the item blocks
+    the feature tables are cut into, both graphs -- lives in the relabelled ids, batches and evaluation lists are translated
+    where they enter and leave, and `gather_tables()` hands the tables back in the dataset's order."""
+
+    relabelled_tables = {'user_embedding.weight': 'u', 'item_id_embedding.weight': 'i'}   # (the row-sharded feature tables: gather_tables)
+    row_order_partial = True      # ... whose optimizer state cannot be re-ordered rank by rank: a checkpoint loads under the same `reorder` only
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -590,18 +603,24 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
 
         self.interaction_matrix = dataset.inter_matrix(form='coo').astype(np.float32)
         self.norm_adj = norm_adj_graph(self.interaction_matrix, nu, ni, self.device)
+        rl = self._setup_relabelling(config, self.norm_adj)     # a function of the full graph: the same on every rank
+        if rl is not None:
+            self.norm_adj = relabel_graph(self.norm_adj, rl.node_perm_host())
         self.masked_adj = None
         rows = torch.from_numpy(self.interaction_matrix.row.astype(np.int64))
         cols = torch.from_numpy(self.interaction_matrix.col.astype(np.int64))
         self.edge_indices = torch.stack([rows, cols]).to(self.device)
         self.edge_values = hip_ops.edge_norm_values(self.edge_indices[0].contiguous(), self.edge_indices[1].contiguous(),
                                                     nu, ni)
+        self.edge_indices = self._map_edges(self.edge_indices)      # (edge ORDER kept: what the per-epoch draw indexes)
 
         # parameters in FREEDOM's construction order on FULL tables (same generator consumption -> the single-process
         # model's initial values), then this rank's columns
         full_u, full_i = nn.Embedding(nu, self.embedding_dim).weight.data, nn.Embedding(ni, self.embedding_dim).weight.data
         nn.init.xavier_uniform_(full_u)
         nn.init.xavier_uniform_(full_i)
+        if rl is not None:            # row `old` of the plain model at relabelled row perm[old]
+            full_u, full_i = full_u[rl.inv_u.cpu()], full_i[rl.inv_i.cpu()]
         cols = slice(self.col_lo, self.col_hi)
         self.user_embedding = nn.Embedding.from_pretrained(full_u[:, cols].contiguous(), freeze=False)
         self.item_id_embedding = nn.Embedding.from_pretrained(full_i[:, cols].contiguous(), freeze=False)
@@ -612,7 +631,10 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         table = LazyRowEmbedding if self.lazy_feature_adam else nn.Embedding
 
         def local_rows(feat):
-            rows_ = feat[self.item_lo:self.item_hi]
+            if rl is None:
+                rows_ = feat[self.item_lo:self.item_hi]
+            else:             # the rank's block of RELABELLED items: relabelled row `new` = dataset row inv_i[new]
+                rows_ = feat.index_select(0, rl.inv_i[self.item_lo:self.item_hi].to(feat.device))
             return rows_.clone() if rows_.shape[0] else feat.new_zeros(1, feat.shape[1])   # an empty block owns nothing
         if self.v_feat is not None:
             self.image_embedding = table.from_pretrained(local_rows(self.v_feat), freeze=False)
@@ -621,9 +643,11 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
             self.text_embedding = table.from_pretrained(local_rows(self.t_feat), freeze=False)
             self.text_trs = nn.Linear(self.t_feat.shape[1], self.feat_embed_dim)
         mm = load_or_build_mm_coo(config, self.v_feat, self.t_feat, self.knn_k, self.mm_image_weight, ni,
-                                  write=self.rank == 0)
+                                  write=self.rank == 0)       # (built / cached in the dataset's ids, like FREEDOM's)
         self.mm_adj = sparse_coo_to_graph(mm, self.device)
         self.mm_adj.transpose()
+        if rl is not None:
+            self.mm_adj = relabel_graph(self.mm_adj, rl.perm_i_host)
         self.has_text, self.has_image = self.t_feat is not None, self.v_feat is not None
         if config['dist_keep_full_features'] is not True:
             self.v_feat = None if self.v_feat is None else self.v_feat[:0]
@@ -682,6 +706,7 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         return _TakeColumns.apply(full, self.col_lo, self.col_hi, self.group, self.multi)
 
     def calculate_loss(self, interaction):
+        interaction = self._map_batch(interaction)              # (`reorder`: the dataset's ids -> the tables' rows)
         users, pos_items, neg_items = interaction[0], interaction[1], interaction[2]
         rows = torch.cat((pos_items, neg_items))
         b = pos_items.shape[0]
@@ -718,8 +743,12 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
         import torch.distributed as tdist
         from mmrec_amd.common.lazy_rows import flush_lazy_tables
         flush_lazy_tables(self)
+        rl = self.relabelling
         out = {'user_embedding.weight': self._all_columns(self.user_embedding.weight.detach()),
                'item_id_embedding.weight': self._all_columns(self.item_id_embedding.weight.detach())}
+        if rl is not None:            # dataset row `old` = relabelled row perm[old]
+            out['user_embedding.weight'] = out['user_embedding.weight'].index_select(0, rl.perm_u)
+            out['item_id_embedding.weight'] = out['item_id_embedding.weight'].index_select(0, rl.perm_i)
         cuts = self.item_cuts
         for name in ('image_embedding', 'text_embedding'):
             if not hasattr(self, name):
@@ -734,7 +763,8 @@ class SlicedFREEDOM(FusedEvalMixin, GeneralRecommender):
                 tdist.all_gather(parts, buf, group=self.group)
             else:
                 parts = [buf]
-            out[name + '.weight'] = torch.cat([p[:cuts[r + 1] - cuts[r]] for r, p in enumerate(parts)], 0)
+            full = torch.cat([p[:cuts[r + 1] - cuts[r]] for r, p in enumerate(parts)], 0)
+            out[name + '.weight'] = full if rl is None else full.index_select(0, rl.perm_i.to(full.device))
         return out
 
     gather_feature_tables = gather_tables

@@ -24,7 +24,7 @@ from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender
 from mmrec_amd.models.freedom import load_or_build_mm_adj
 
 
-def global_subgraph(norm_adj, q, device, block=2048, tol=1e-3):
+def global_subgraph(norm_adj, q, device, block=None, tol=1e-3):
     """PGL's `global_subgraph_extraction` (pgl.py:138-153): rank-(q/4) spectral sub-graph
         S = U[:, :m] diag(s[:m] * s[q-m:]) V[:, :m]^T,  m = int(0.25 q),  entries with |S| < 1e-3 dropped,
     from the q leading singular triplets of the normalised adjacency.  The reference takes them from the third-party
@@ -33,17 +33,32 @@ def global_subgraph(norm_adj, q, device, block=2048, tol=1e-3):
     their vectors -- on ARPACK (`scipy.sparse.linalg.svds`): S is the same matrix for any orthonormal basis of a repeated
     singular value's subspace (the symmetric bipartite adjacency has every singular value twice; U and V rotate together and
     the two weights of a pair are equal), so only entries within rounding of the 1e-3 cut can differ between solvers.
-    The [N, N] product is formed `block` rows at a time (the reference materialises it densely: 2.8 GB at Amazon-Baby size)."""
+    That argument needs the three cuts -- after triplet m, before triplet q - m, after triplet q -- to fall BETWEEN pairs, which
+    an odd m (embedding_size 36: m = 9) or a pair the solver returned one copy of breaks: two more triplets than needed are
+    requested, the three boundaries are looked at, and a cut pair is reported (the sub-graph then depends on the solver's basis
+    of that pair beyond the 1e-3 cut; round-5 advice).
+    The [N, N] product is formed `block` rows at a time (default: ~1 GB of fp32 per block; the reference materialises it
+    densely: 2.8 GB at Amazon-Baby size)."""
+    import logging
     import scipy.sparse as sp
     from scipy.sparse.linalg import svds
     idx, val = norm_adj.to_coo_host()
     n = norm_adj.n_rows
     a = sp.csc_matrix((val.astype(np.float64), (idx[0], idx[1])), shape=(n, n))
     k = min(int(q), n - 2)
-    u, s_, vt = svds(a, k=k, which='LM', tol=1e-10, v0=np.ones(n))      # ascending singular values, deterministic start vector
+    k_req = min(k + 2, n - 2)
+    u, s_, vt = svds(a, k=k_req, which='LM', tol=1e-10, v0=np.ones(n))  # ascending singular values, deterministic start vector
     order = np.argsort(-s_, kind='stable')
     u, s_, vt = u[:, order], s_[order], vt[order]
     m = int(0.25 * q)
+    cut = [j for j in (m, k - m, k) if 0 < j < k_req and abs(s_[j - 1] - s_[j]) <= 1e-7 * max(abs(s_[j - 1]), 1e-30)]
+    if cut:
+        logging.getLogger().warning('PGL global sub-graph: the cut after singular triplet(s) %s of %d falls inside a pair of equal '
+                                    'singular values (m = %d): the sub-graph depends on the solver\'s basis of that pair -- parity '
+                                    'with the reference\'s sparsesvd is not expected beyond the 1e-3 cut' % (cut, k, m))
+    u, s_, vt = u[:, :k], s_[:k], vt[:k]
+    if block is None:
+        block = int(max(16, min(2048, (1 << 28) // max(n, 1))))
     w = s_[:m] * s_[k - m:k]
     left = (u[:, :m] * w[None, :]).astype(np.float32)
     right = vt[:m].astype(np.float32)

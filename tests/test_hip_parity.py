@@ -1782,7 +1782,7 @@ def test_sharded_propagator_rccl_single_rank(ops, dev):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("layout", ["rows", "dslice"])
+@pytest.mark.parametrize("layout", ["rows", "dslice", "dslice+reorder"])
 def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
     """config `n_gpus`: the sharded FREEDOM plugins on the HIP kernels through a single-rank RCCL group, collectives forced:
     one epoch of Trainer steps and an evaluation == the plain FREEDOM plugin.  `dist_layout: rows` -- row-sharded graphs +
@@ -1790,13 +1790,16 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
     sharded evaluation; `dslice` -- the feature-sliced plugin (whole graphs, column-sliced id tables, all-reduced partial dot
     products, full-width projection gradients summed back to the owners, tables all-gathered per evaluation).  World sizes
     2 / 3 / 4 / 8 run on gloo with the CPU stand-ins (tests/test_dist_gloo.py); the slice kernels themselves are checked bit
-    for bit above (test_spmm_feature_slices_equal_the_d64_launch_bitwise)."""
+    for bit above (test_spmm_feature_slices_equal_the_d64_launch_bitwise).  `dslice+reorder`: the sliced plugin with config
+    `reorder: community` (tables, item blocks and graphs in relabelled ids; the device label propagation) against the PLAIN
+    plugin without the key."""
     import os
     import socket
     import torch.distributed as dist
     from mmrec_amd.common.trainer import Trainer
     from mmrec_amd.utils.utils import get_model
     from tests._env import setup
+    layout, reorder = (layout.split("+") + [None])[:2]
     single_rank_rccl_group(dev)
     try:
         res = {}
@@ -1804,10 +1807,13 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
             extra = {"dropout": 0.8, "reg_weight": 1e-3, "learning_rate": 0.01, "dist_chunks": 2,
                      "dist_force_collectives": True, "lazy_feature_adam": False, "dist_layout": layout,
                      "hip_pull_batch_rows": sharded}     # the sliced plugin at the batch rows against the plain one over all rows
+            if reorder and sharded:
+                extra["reorder"] = "community"
             config, train_data, valid_data = setup(tmp_path / ("s%d" % sharded), golden, "FREEDOM", extra, use_gpu=True)
             model = get_model("FREEDOM", sharded=sharded)(config, train_data).to(config["device"])
             assert type(model).__name__ == {(False, layout): "FREEDOM", (True, "rows"): "RowShardedFREEDOM",
                                             (True, "dslice"): "SlicedFREEDOM"}[(sharded, layout)]
+            assert (model.relabelling is not None) == bool(reorder and sharded)
             gen = torch.Generator().manual_seed(3)
             keep = torch.multinomial(model.edge_values.detach().cpu(), int(model.edge_values.numel() * 0.2), generator=gen)
             model.set_kept_edges(keep.to(dev))

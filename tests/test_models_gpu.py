@@ -1302,6 +1302,75 @@ def test_freedom_relabelled_id_space_is_bitwise_the_plain_model(tmp_path, golden
                 torch.testing.assert_close(b[1][n], a[1][n], rtol=1e-5, atol=1e-9, msg=n)
 
 
+def test_optimizer_checkpoint_is_in_dataset_row_order_under_reorder(tmp_path, golden):
+    """Round-5 advice: under `reorder` the Adam moments (and the row-lazy tables' bookkeeping) live in the relabelled row order.
+    The Trainer registers the tables' permutations with HipAdam, whose state_dict then holds per-row state in the DATASET's
+    order, like the model's: three deterministic steps under `reorder: degree`, {model, optimizer} saved, loaded into a PLAIN
+    model + optimizer (no key), three more steps == six uninterrupted steps of the plain model, bit for bit (and the same the
+    other way round: plain checkpoint resumed under `reorder: rcm`); the saved moments of the relabelled run equal the plain
+    run's at the save point row by row."""
+    if not USE_GPU:
+        pytest.skip("HipAdam is HIP kernels")
+    import copy
+    from mmrec_amd import hip_ops
+    from mmrec_amd.common.lazy_rows import flush_lazy_tables
+    from mmrec_amd.common.trainer import Trainer
+    batch = torch.as_tensor(golden["batch"][:3])
+
+    def make(tag, key):
+        extra = {"dropout": 0.8, "reg_weight": 1e-3, "hip_deterministic": True, "hip_graph_step": False,
+                 "lazy_feature_adam": True, "learning_rate": 1e-2}
+        if key:
+            extra["reorder"] = key
+        config, _, _, model = build(tmp_path / tag, golden, "FREEDOM", extra)
+        for k, v in extra.items():
+            config[k] = v
+        trainer = Trainer(config, model)
+        hip_ops.set_deterministic(True)
+        model.set_kept_edges(torch.as_tensor(golden["fr_keep_idx"]).to(model.device))
+        model.train()
+        return model, trainer
+
+    def steps(model, trainer, lo, hi):
+        for step in range(lo, hi):
+            b = torch.roll(batch, shifts=17 * step, dims=1)[:, :64 + 16 * step].to(model.device)
+            trainer.optimizer.zero_grad()
+            model.calculate_loss(b).backward()
+            trainer.optimizer.step()
+
+    try:
+        plain, tp = make("plain", None)
+        init = {k: v.clone() for k, v in plain.state_dict().items()}
+        steps(plain, tp, 0, 3)
+        mid_opt = copy.deepcopy(tp.optimizer.state_dict())      # (torch hands out the live state tensors)
+        mid_model = {k: v.clone() for k, v in plain.state_dict().items()}
+        steps(plain, tp, 3, 6)
+        flush_lazy_tables(plain)
+        ref = {k: v.clone() for k, v in plain.state_dict().items()}
+        for first, second in (("degree", None), (None, "rcm")):
+            a, ta = make("a%s" % first, first)
+            a.load_state_dict(init)
+            steps(a, ta, 0, 3)
+            sd_opt, sd_model = copy.deepcopy(ta.optimizer.state_dict()), {k: v.clone() for k, v in a.state_dict().items()}
+            assert (sd_opt["mmrec_row_order"] is not None) == bool(first)
+            for k in mid_model:
+                assert torch.equal(sd_model[k], mid_model[k]), k
+            for i, st in mid_opt["state"].items():               # per-row state in the dataset's order either way
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        assert torch.equal(sd_opt["state"][i][k], v), (i, k)
+            b, tb = make("b%s" % second, second)
+            b.load_state_dict(sd_model)
+            tb.optimizer.load_state_dict(sd_opt)
+            steps(b, tb, 3, 6)
+            flush_lazy_tables(b)
+            got = b.state_dict()
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (first, second, k)
+    finally:
+        hip_ops.set_deterministic(False)
+
+
 @pytest.mark.parametrize("name,extra,keep", [("LightGCN", {"n_layers": 3, "reg_weight": 1e-4}, None),
                                              ("LayerGCN", {"n_layers": 4, "reg_weight": 1e-3, "dropout": 0.1}, "lay_keep_idx")])
 def test_relabelled_id_space_other_plugins_on_device(tmp_path, golden, name, extra, keep):
