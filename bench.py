@@ -640,6 +640,25 @@ def extra_baby(dev):
     # the backward's write roofline: dX is n x 4096 fp32 written once (kernel time from the in-run counters pass below)
     out["projection_roofline"]["baby"]["dx_bytes_written"] = 4.0 * ni * 4096
     Xg.grad = Wg.grad = bg.grad = None
+    del Xg, G
+    try:      # the same call at Amazon-Sports size (18,357 items: X = 301 MB streams from HBM, 144 row blocks -> three chunks each)
+        ns = 18357
+        Xs = torch.rand(ns, 4096, device=dev, generator=gen).requires_grad_()
+        Gs = torch.rand(ns, 64, device=dev, generator=gen) - 0.5
+
+        def fwd_bwd_sports():
+            Xs.grad = Wg.grad = bg.grad = None
+            hip_ops.linear(Xs, Wg, bg).backward(Gs)
+        sts = graph_timeit(fwd_bwd_sports, reps=50, windows=5, warm=5)
+        with torch.no_grad():
+            dts = timeit(lambda: hip_ops.linear(Xs, Wg, bg), reps=50, warm=10, windows=3)
+        out["projection_roofline"]["sports"] = {"n": ns, "F": 4096, "fwd_bwd_us": sts["median"] * 1e6,
+                                                "fwd_bwd_us_min_max": [sts["min"] * 1e6, sts["max"] * 1e6], "mode": sts["mode"],
+                                                "fwd_us_eager": dts * 1e6, "x_gbs_fwd_eager": 4.0 * ns * 4096 / dts / 1e9}
+        Xs.grad = Wg.grad = bg.grad = None
+        del Xs, Gs
+    except Exception as ex:
+        out["projection_roofline"]["sports"] = {"error": repr(ex)}
     for key, lazy in (("baby_freedom_train_step", False), ("baby_freedom_train_step_lazy", True)):
         reps, windows, warm = 20, 5, 3
         step = make_freedom_step(dev, nu, ni, eu, ei, gen, lazy=lazy, capturable=True)
@@ -1501,6 +1520,21 @@ def emit_line(args, rank, world, multi, sh, g, r, c, v, dev, n_nodes, nnz_total,
                                                                                  c[:ne] - sh.n_users)
             except Exception as ex:
                 line["extra"]["c5_train_step_roofline"] = {"error": repr(ex)}
+            try:      # round 6: the row-lazy Adam's catch-up of a late config-5 step, exact replay against the opt-in closed form
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import prof_adam_catchup
+                key = "exponential gaps, mean 122 (the late config-5 step)"
+                got = prof_adam_catchup.measure(dev, shapes=(key,), log=log)[key]
+                line["extra"]["lazy_adam_catchup"] = {
+                    "exact_replay_us": got["exact_us"], "closed_form_us": got["closed_form_us"], "rows": 4096, "columns": 4096,
+                    "optimizer_step": 683, "bytes_streamed": 4096 * 4096 * 24.0,
+                    "closed_form_gbs": 4096 * 4096 * 24.0 / (got["closed_form_us"] * 1e-6) / 1e9,
+                    "what": "mmrec_adam_rows_catchup_f32 (the default: dense Adam's bits) against mmrec_adam_rows_fastforward_f32 (config "
+                            "lazy_adam_fast_forward, opt-in: as close to float64 Adam as the dense kernel, not bit-identical) on 4,096 "
+                            "listed rows of a [*, 4096] table whose gaps since the last visit are drawn like a config-5 run's after "
+                            "680 steps"}
+            except Exception as ex:
+                line["extra"]["lazy_adam_catchup"] = {"error": repr(ex)}
             if not args.no_configs:
                 # round-5 review, next 2: Trainer-level ms per batch of VBPR and the five models north_star names, at their
                 # BASELINE shapes, through the plugin API (tools/run_config.py; the committed profiles/rNN_run_configs.json of

@@ -14,9 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmrec_amd import _lib  # noqa: E402
 
 
-def main():
-    F = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    dev = torch.device("cuda:0")
+def measure(dev, F=4096, shapes=None, log=print):
+    """-> {shape name: {"exact_us", "closed_form_us", "element_steps"}} (min of three timed launches each, state restored)"""
     lib = _lib.load()
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     n, t_now, b1, b2, eps, lr = 4096, 683, 0.9, 0.999, 1e-8, 1e-3
@@ -30,14 +29,17 @@ def main():
     ids = torch.arange(n, device=dev, dtype=torch.int64)
     owner = torch.full((n,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
     rng = np.random.default_rng(0)
-    shapes = {"exponential gaps, mean 122 (the late config-5 step)": np.clip(rng.exponential(122, n), 1, t_now - 1).astype(np.int32),
-              "every gap 122": np.full(n, 122, np.int32), "every gap 13": np.full(n, 13, np.int32),
-              "every gap 600 (last touched at step 83: the series is refused)": np.full(n, 600, np.int32),
-              "every gap 400": np.full(n, 400, np.int32)}
-    for what, gaps in shapes.items():
+    every = {"exponential gaps, mean 122 (the late config-5 step)": np.clip(rng.exponential(122, n), 1, t_now - 1).astype(np.int32),
+             "every gap 122": np.full(n, 122, np.int32), "every gap 13": np.full(n, 13, np.int32),
+             "every gap 600 (last touched at step 83: replayed to step 128, closed form from there)": np.full(n, 600, np.int32),
+             "every gap 400": np.full(n, 400, np.int32)}
+    out = {}
+    for what, gaps in every.items():
+        if shapes is not None and what not in shapes:
+            continue
         last0 = torch.from_numpy(t_now - gaps).to(dev)
-        line = "%-66s element-steps %.2e:" % (what, float(gaps.sum()) * F)
-        for name, fn in (("exact", lib.mmrec_adam_rows_catchup_f32), ("closed form", lib.mmrec_adam_rows_fastforward_f32)):
+        res = {"element_steps": float(gaps.sum()) * F}
+        for name, fn in (("exact", lib.mmrec_adam_rows_catchup_f32), ("closed_form", lib.mmrec_adam_rows_fastforward_f32)):
             times = []
             for rep in range(4):
                 p, m, v, last = p0.clone(), m0.clone(), v0.clone(), last0.clone()
@@ -49,9 +51,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times.append(e0.elapsed_time(e1) * 1e3)
-            line += "  %s %.0f us" % (name, min(times[1:]))
-        print(line + "   (streaming p, m, v of the rows once each way: %.0f MB)" % (n * F * 24 / 1e6), flush=True)
+            res[name + "_us"] = min(times[1:])
+        log("%-88s element-steps %.2e:  exact %.0f us  closed form %.0f us   (streaming p, m, v of the rows once each way: %.0f MB)"
+            % (what, res["element_steps"], res["exact_us"], res["closed_form_us"], n * F * 24 / 1e6))
+        out[what] = res
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    measure(torch.device("cuda:0"), int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
