@@ -816,7 +816,7 @@ def test_linear_fwd_bwd(ops, dev, n, F, bias):
         close(bd.grad, b.grad, atol=1e-4)
 
 
-@pytest.mark.parametrize("n,F", [(3000, 4096), (7050, 384), (513, 4480), (40_000, 4096)])
+@pytest.mark.parametrize("n,F", [(3000, 4096), (7050, 384), (513, 4480), (40_000, 4096), (18_357, 4096), (16_600, 1024)])
 def test_linear_split_forward_is_as_accurate_as_the_fp32_kernel(ops, dev, n, F):
     """mmrec_linear_fwd_split_f32 (ABI 8; hip_ops.LINEAR_F16X3, the default): the projection's forward as three fp16 MFMA products
     of split operands x = hi + 2^-11 lo'.  Against float64 its error is within 2 x the fp32-MFMA kernel's (both ~1e-7 of the
@@ -847,14 +847,15 @@ def test_linear_split_forward_is_as_accurate_as_the_fp32_kernel(ops, dev, n, F):
     assert torch.equal(out[True][3], out[False][3])              # the zero row: bias only, exactly
 
 
-@pytest.mark.parametrize("n,F", [(1000, 4096), (7050, 384), (40_000, 4096), (300_000, 128)])
+@pytest.mark.parametrize("n,F", [(1000, 4096), (7050, 384), (40_000, 4096), (300_000, 128), (18_357, 4096), (16_600, 1024)])
 def test_linear_split_domain_guard(ops, dev, n, F):
     """The split-operand forward is the DEFAULT projection, so it has to be a drop-in for fp32 `nn.Linear` (freedom.py:205,208;
     bm3.py:102-104) over ALL of fp32's range, not only where fp16 holds the two halves: rows of tiny magnitude (1e-7, 1e-8: fp16
     subnormals), of huge magnitude (5e4 < 65504 still inside; 1e5, 3e38 outside), inf and NaN.  No bias, error measured against
     sum |x_k w_k| ALONE (a bias of size 1 would hide a 1e-6-scaled row), <= 1e-6; non-finite rows propagate exactly as the
     fp32 kernel's (= F.linear's) do; rows in the same 128-row block as a flagged row and all other rows are unharmed.  Shapes:
-    one slab per row block (40,000 x 4096; 300,000 x 128) and split-K (1000 x 4096, 7050 x 384: maxima combined over slabs)."""
+    one slab per row block (300,000 x 128), split-K (1000 x 4096, 7050 x 384: maxima combined over slabs) and the stream-K grid
+    from 129 row blocks (18,357 and 16,600 rows: a block's tiles in two or three segments; 40,000: runs that span two blocks)."""
     g = torch.Generator().manual_seed(n + F)
     X = torch.relu(torch.randn(n, F, generator=g))
     W = torch.randn(64, F, generator=g) / F ** 0.5
