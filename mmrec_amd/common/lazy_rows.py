@@ -268,7 +268,8 @@ class LazyRowEmbedding(nn.Embedding):
         return True
 
 
-AUTO_MIN_ELEMENTS = 64 << 20   # automatic mode: tables from 64 Mi elements (256 MB) up
+AUTO_MIN_ELEMENTS = 64 << 20   # automatic mode, eager steps: tables from 64 Mi elements (256 MB) up
+AUTO_MIN_ELEMENTS_REPLAYED = 16 << 20   # ... steps replayed as a hipGraph (`hip_graph_step` auto / True: the default): from 16 Mi
 
 
 def lazy_adam_enabled(config, n_elements=0):
@@ -276,12 +277,18 @@ def lazy_adam_enabled(config, n_elements=0):
     (learner adam, hip_fused_adam on, GPU; eager or replayed as a hipGraph); the update is bit-identical either way.
     Automatic mode turns it on for large tables only: the ~20 extra small launches of a step cost ~0.25 ms, more than
     dense Adam over the Amazon-Baby tables (31.6 M elements: 0.17 ms; measured 0.76 -> 1.02 ms per step), less than
-    it from Sports (75 M: 1.90 -> 1.73 ms) and Clothing (3.36 -> 2.50 ms) up, 4.6 x at 500K items."""
+    it from Sports (75 M: 1.90 -> 1.73 ms) and Clothing (3.36 -> 2.50 ms) up, 4.6 x at 500K items.  Those were EAGER steps;
+    replayed as a hipGraph (the default for the plugins that use these tables) the extra launches cost a few microseconds each
+    and the row-lazy form wins at the Amazon-Baby tables too (Trainer level, FREEDOM: 0.87 -> 0.67 ms per batch, identical
+    losses; profiles/r06_lazy_adam_auto_threshold.log), so the automatic threshold is 16 Mi elements when `hip_graph_step` is
+    not switched off."""
     want = config['lazy_feature_adam']
     ok = (str(config['learner']).lower() == 'adam' and config['hip_fused_adam'] in (None, True) and
           not config['clip_grad_norm'] and    # clipping needs the dense .grad
           getattr(config['device'], 'type', str(config['device'])) == 'cuda')
-    return (ok and n_elements >= AUTO_MIN_ELEMENTS) if want is None else (bool(want) and ok)
+    replayed = config['hip_graph_step'] is not False and str(config['hip_graph_step']).lower() not in ('false', 'off', 'none')
+    need = AUTO_MIN_ELEMENTS_REPLAYED if replayed else AUTO_MIN_ELEMENTS
+    return (ok and n_elements >= need) if want is None else (bool(want) and ok)
 
 
 def flush_lazy_tables(module):

@@ -157,6 +157,9 @@ def _run_vs_reference(tmp_path, model_name, hyper, tag):
     res = trainer.evaluate(valid_data)
     for k, v in zip(g[tag + "metric_keys"], g[tag + "metrics"]):
         assert abs(res[str(k)] - v) <= 1e-4 + 1e-12, (k, res[str(k)], v)
+    from mmrec_amd.common.lazy_rows import flush_lazy_tables
+    flush_lazy_tables(model)        # (round 6: the row-lazy Adam is automatic at this size when the step is replayed; rows the epoch's
+                                    #  last batches did not touch hold postponed updates until the table is read as a whole -- state_dict does this)
     for name, p in model.named_parameters():
         if name.endswith("trs.bias"):
             continue                                  # analytically-zero gradient: Adam-normalised rounding noise

@@ -212,7 +212,12 @@ def test_config_helpers_for_added_keys():
     assert eval_batch_size(Cfg(base, device=gpu)) == 65536
     assert eval_batch_size(Cfg(base, device=gpu, hip_eval_batch_size=10000)) == 10000
     assert eval_batch_size(Cfg(base, device=gpu, hip_fused_eval=False)) == 4096
-    big, small = AUTO_MIN_ELEMENTS, AUTO_MIN_ELEMENTS - 1
+    from mmrec_amd.common.lazy_rows import AUTO_MIN_ELEMENTS_REPLAYED
+    big, small = AUTO_MIN_ELEMENTS, AUTO_MIN_ELEMENTS_REPLAYED - 1
+    assert lazy_adam_enabled(Cfg(base, device=gpu, hip_graph_step=False), big)
+    assert not lazy_adam_enabled(Cfg(base, device=gpu, hip_graph_step=False), big - 1)       # eager steps: from 64 Mi elements
+    for replayed in ("auto", True):                                                           # replayed steps (the default): from 16 Mi
+        assert lazy_adam_enabled(Cfg(base, device=gpu, hip_graph_step=replayed), AUTO_MIN_ELEMENTS_REPLAYED)
     assert lazy_adam_enabled(Cfg(base, device=gpu), big) and not lazy_adam_enabled(Cfg(base, device=gpu), small)
     assert lazy_adam_enabled(Cfg(base, device=gpu, lazy_feature_adam=True), small)
     assert not lazy_adam_enabled(Cfg(base, device=gpu, lazy_feature_adam=False), big)

@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="hip_deterministic: position-ordered gradient scatters")
     ap.add_argument("--no-batch-rows", action="store_true", help="FREEDOM: hip_pull_batch_rows False (launches over all rows)")
     ap.add_argument("--fp32-linear", action="store_true", help="hip_linear_split False: projection forward + backward on the fp32-MFMA kernels")
+    ap.add_argument("--lazy-adam", action="store_true", help="force the row-lazy exact Adam on the feature tables (automatic from 64 Mi elements)")
+    ap.add_argument("--fast-forward", action="store_true", help="lazy_adam_fast_forward: closed-form catch-up (opt-in, not bit-identical)")
     args = ap.parse_args()
     cd = dict(device_neg_sampling=args.device_neg_sampling)
     if args.graph_step or args.eager:
@@ -116,6 +118,10 @@ def main():
         cd['lazy_prefetch'] = False
     if args.dense_adam:
         cd['lazy_feature_adam'] = False
+    if args.lazy_adam:
+        cd['lazy_feature_adam'] = True
+    if args.fast_forward:
+        cd['lazy_adam_fast_forward'] = True
     if args.deterministic:
         cd['hip_deterministic'] = True
     if args.no_batch_rows:
