@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMREC_ABI_VERSION 13
+#define MMREC_ABI_VERSION 14
 #define MMREC_EMB_DIM 64 /* embedding_size the SpMM / BPR / top-K kernels are specialised for (overall.yaml:16) */
 
 #define MMREC_ERR_BAD_ARG 10001      /* null pointer / negative size / unsupported d or k */
@@ -186,6 +186,22 @@ int mmrec_gather_sqnorm_fwd_f32(const float* E, const int64_t* ids, int32_t batc
                                 float* out, void* workspace, mmrec_stream_t stream);
 int mmrec_gather_scale_add_bwd_f32(const float* E, const int64_t* ids, int32_t batch, int32_t d,
                                    const float* coef_scalar, float* dE, mmrec_stream_t stream);
+/* ABI 14 -- the whole regulariser of a training step in one forward call (two launches) and one backward launch:
+ *   out[0] = scale * sum_t f(S_t),  S_t = sum_b ||E[t][ids[t][b]]||^2,  mode 0: f = identity (the L2 regulariser on the
+ *   batch's rows: layergcn.py:154-161, lattice.py:214-216), mode 1: f = sqrt (EmbLoss: common/loss.py:46-51 as used at
+ *   vbpr.py:95, lightgcn.py:145-149); n_terms <= MMREC_ROWS_REG_MAX_TERMS, batch[t] rows per term, rows of d = 64 k floats.
+ *   coef[t] (out, device) = the factor of the backward: dE[t][ids[t][b]] += g[0] * coef[t] * E[t][ids[t][b]] (fp32 atomics;
+ *   two terms may name the same E / dE: the item table's positive and negative rows).  A term whose S_t is 0 gets coef 0 in
+ *   mode 1, as torch.norm's backward does.  E, ids, batch, dE are HOST arrays of n_terms entries (copied into the launch).
+ * replaces: the per-term mmrec_gather_sqnorm_fwd_f32 / mmrec_gather_scale_add_bwd_f32 calls and the ~20 elementwise
+ * launches between them (a quarter of a LayerGCN / VBPR step at Amazon-Baby size). */
+#define MMREC_ROWS_REG_MAX_TERMS 6
+size_t mmrec_rows_reg_workspace_bytes(int32_t n_terms, int32_t max_batch);
+int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms, int32_t d,
+                           int32_t mode, float scale, float* out, float* coef, void* workspace, mmrec_stream_t stream);
+int mmrec_rows_reg_bwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms, int32_t d,
+                           const float* coef, const float* g, float* const* dE, mmrec_stream_t stream);
+
 
 /* In-batch InfoNCE between two views of the same ids (d = 64), logits never materialised:
  *   v1 = normalize(E1[ids]), v2 = normalize(E2[ids])  (F.normalize, eps 1e-12)

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MMREC_HIP_LIB: load another build of the same library (kernel A/B measurements: tools/prof_topk_filter.py)
 LIB_PATH = os.environ.get("MMREC_HIP_LIB") or os.path.join(_PKG, "lib", "libmmrec_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _P = c_void_p  # every device/host pointer travels as void*
 
@@ -85,6 +85,9 @@ SIGNATURES = {
     "mmrec_cosine_workspace_bytes": (c_size_t, [c_int32]),
     "mmrec_cosine_fwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, _P, _P, _P]),
     "mmrec_cosine_bwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, _P, c_float, _P, _P]),
+    "mmrec_rows_reg_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "mmrec_rows_reg_fwd_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P]),
+    "mmrec_rows_reg_bwd_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     "mmrec_adam_hist_set": (c_int32, [_P, c_int32, c_float, c_float, c_float, _P]),
     "mmrec_adam_rows_owner": (c_int32, [_P, c_int32, _P, _P]),
     "mmrec_adam_rows_catchup_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_int32, c_float,

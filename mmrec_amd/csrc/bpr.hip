@@ -165,6 +165,75 @@ __global__ __launch_bounds__(256) void gather_scale_add_kernel(const float* __re
     }
 }
 
+// ---- the regulariser of a training step in ONE forward and ONE backward launch pair (ABI 14) --------------------------------
+// reg = scale * sum_t f(S_t),  S_t = sum_b ||E_t[ids_t[b]]||^2,  f = identity (mode 0: the L2 regulariser on batch rows,
+// layergcn.py:154-161, lattice.py:214-216) or sqrt (mode 1: EmbLoss, common/loss.py:46-51 as used at vbpr.py:95,
+// lightgcn.py:145-149, bpr.py).  A step used to spend ~11 launches forward (per term: row norms, their sum, a sqrt, the adds
+// and scalings around them) and ~13 backward for its three terms -- a quarter of a LayerGCN / VBPR step at Amazon-Baby size,
+// where every launch is ~4.5 us of a 0.35 ms step.  Here: row norms of ALL terms (grid.y = term), then one workgroup sums each
+// term in fixed order (reduce_sum_kernel's), forms reg and leaves coef[t] = d reg / d row scale (2 scale, or scale / sqrt(S_t),
+// 0 where S_t = 0 as torch.norm's backward does); backward: dE_t[ids_t[b]] += g coef[t] E_t[ids_t[b]] for all terms at once.
+struct RegTerms {
+    const float* E[MMREC_ROWS_REG_MAX_TERMS];
+    const int64_t* ids[MMREC_ROWS_REG_MAX_TERMS];
+    float* dE[MMREC_ROWS_REG_MAX_TERMS];
+    int batch[MMREC_ROWS_REG_MAX_TERMS];
+    int n_terms, max_batch;
+};
+
+__global__ __launch_bounds__(256) void rows_reg_sq_kernel(const RegTerms a, int d4, float* __restrict__ sq) {
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= a.batch[t]) return;
+    const float4* row = reinterpret_cast<const float4*>(a.E[t]) + (size_t)a.ids[t][b] * d4;
+    float x = 0.f;
+    for (int k = lane16; k < d4; k += 16) {
+        const float4 e = row[k];
+        x += f4_dot(e, e);
+    }
+    const float s = row16_sum(x);
+    if (lane16 == 0) sq[(size_t)t * a.max_batch + b] = s;
+}
+
+__global__ __launch_bounds__(256) void rows_reg_finish_kernel(const RegTerms a, const float* __restrict__ sq, int mode, float scale,
+                                                              float* __restrict__ out, float* __restrict__ coef) {
+    __shared__ float red[256];
+    float total = 0.f;
+    for (int t = 0; t < a.n_terms; ++t) {
+        float x = 0.f;
+        for (int i = threadIdx.x; i < a.batch[t]; i += 256) x += sq[(size_t)t * a.max_batch + i];
+        red[threadIdx.x] = x;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        const float S = red[0];
+        __syncthreads();
+        if (mode == 0) {
+            total += S;
+            if (threadIdx.x == 0) coef[t] = 2.f * scale;
+        } else {
+            const float nrm = sqrtf(S);
+            total += nrm;
+            if (threadIdx.x == 0) coef[t] = S > 0.f ? scale / nrm : 0.f;
+        }
+    }
+    if (threadIdx.x == 0) out[0] = scale * total;
+}
+
+__global__ __launch_bounds__(256) void rows_reg_bwd_kernel(const RegTerms a, int d4, const float* __restrict__ coef,
+                                                           const float* __restrict__ g) {
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= a.batch[t]) return;
+    const float c = g[0] * coef[t];
+    for (int k = lane16; k < d4; k += 16) {
+        const size_t i = (size_t)a.ids[t][b] * d4 + k;
+        atomic_add_f4(a.dE[t] + i * 4, f4_scale(c, reinterpret_cast<const float4*>(a.E[t])[i]));
+    }
+}
+
 // mean_b cos(X[ix[b]], Y[iy[b]]) with F.cosine_similarity's clamp (each norm at least 1e-8) -- BM3's six BYOL terms
 // (bm3.py:129-144; the targets Y are detached there: gradient w.r.t. X only).  ix / iy == nullptr: row b itself.
 // coef[b] = {1 / (nx ny), cos / nx^2 (0 where the clamp is active)}: dcos/dx = coef.x * y - coef.y * x.
@@ -339,6 +408,53 @@ extern "C" int mmrec_gather_scale_add_bwd_f32(const float* E, const int64_t* ids
     if (!E || !ids || !coef_scalar || !dE) return MMREC_ERR_BAD_ARG;
     hipLaunchKernelGGL(gather_scale_add_kernel, dim3((batch + 15) / 16), dim3(256), 0,
                        mmrec_stream(stream), E, ids, batch, d / 4, coef_scalar, dE);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+namespace {
+int reg_terms(RegTerms& a, const float* const* E, const int64_t* const* ids, float* const* dE, const int32_t* batch,
+              int32_t n_terms) {
+    if (n_terms < 1 || n_terms > MMREC_ROWS_REG_MAX_TERMS || !E || !ids || !batch) return MMREC_ERR_BAD_ARG;
+    a.n_terms = n_terms, a.max_batch = 0;
+    for (int t = 0; t < n_terms; ++t) {
+        if (batch[t] < 0 || (batch[t] > 0 && (!E[t] || !ids[t] || (dE && !dE[t])))) return MMREC_ERR_BAD_ARG;
+        a.E[t] = E[t], a.ids[t] = ids[t], a.dE[t] = dE ? dE[t] : nullptr, a.batch[t] = batch[t];
+        if (batch[t] > a.max_batch) a.max_batch = batch[t];
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t mmrec_rows_reg_workspace_bytes(int32_t n_terms, int32_t max_batch) {
+    return (size_t)(n_terms > 0 ? n_terms : 0) * (size_t)(max_batch > 0 ? max_batch : 0) * sizeof(float) + 16;
+}
+
+extern "C" int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms,
+                                      int32_t d, int32_t mode, float scale, float* out, float* coef, void* workspace,
+                                      mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;  // rows of 64, 128, ... floats
+    if (mode != 0 && mode != 1) return MMREC_ERR_BAD_ARG;
+    RegTerms a;
+    if (int err = reg_terms(a, E, ids, nullptr, batch, n_terms)) return err;
+    if (!out || !coef || !workspace) return MMREC_ERR_BAD_ARG;
+    hipStream_t s = mmrec_stream(stream);
+    float* sq = static_cast<float*>(workspace);
+    if (a.max_batch > 0)
+        hipLaunchKernelGGL(rows_reg_sq_kernel, dim3((a.max_batch + 15) / 16, n_terms), dim3(256), 0, s, a, d / 4, sq);
+    hipLaunchKernelGGL(rows_reg_finish_kernel, dim3(1), dim3(256), 0, s, a, (const float*)sq, mode, scale, out, coef);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_rows_reg_bwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms,
+                                      int32_t d, const float* coef, const float* g, float* const* dE, mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    RegTerms a;
+    if (!dE) return MMREC_ERR_BAD_ARG;
+    if (int err = reg_terms(a, E, ids, dE, batch, n_terms)) return err;
+    if (!coef || !g) return MMREC_ERR_BAD_ARG;
+    if (a.max_batch == 0) return 0;
+    hipLaunchKernelGGL(rows_reg_bwd_kernel, dim3((a.max_batch + 15) / 16, n_terms), dim3(256), 0, mmrec_stream(stream), a, d / 4,
+                       coef, g);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

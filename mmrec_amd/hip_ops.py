@@ -973,6 +973,69 @@ def gather_sqnorm(E, ids):
     return _GatherSqNorm.apply(E, ids)
 
 
+class _RowsReg(torch.autograd.Function):
+    """scale * sum_t f(sum_b ||E_t[ids_t[b]]||^2) for ALL terms of a step's regulariser: mmrec_rows_reg_fwd_f32 / _bwd_f32
+    (ABI 14).  Inputs: mode, scale, then E_0, ids_0, E_1, ids_1, ...; a table that appears in several terms (the item table's
+    positive and negative rows) gets ONE dense gradient buffer, returned for its first occurrence."""
+
+    @staticmethod
+    def forward(ctx, mode, scale, *flat):
+        lib = _lib.load()
+        tables = [_chk(flat[2 * t].contiguous(), torch.float32, "E", 2) for t in range(len(flat) // 2)]
+        ids = [_chk(flat[2 * t + 1], torch.int64, "ids", 1) for t in range(len(flat) // 2)]
+        n, d, dev = len(tables), tables[0].shape[1], tables[0].device
+        if any(E.shape[1] != d for E in tables) or d % EMB_DIM:
+            raise _lib.MMRecHipError("rows_reg: every table needs the same row width, a multiple of %d" % EMB_DIM)
+        batch = (ctypes.c_int32 * n)(*[i.numel() for i in ids])
+        ctx.arrays = ((ctypes.c_void_p * n)(*[E.data_ptr() for E in tables]), (ctypes.c_void_p * n)(*[i.data_ptr() for i in ids]), batch)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = _ws(lib.mmrec_rows_reg_workspace_bytes(n, max(batch)), dev)
+        _lib.check(lib.mmrec_rows_reg_fwd_f32(ctx.arrays[0], ctx.arrays[1], batch, n, d, int(mode), float(scale), _p(out), _p(coef),
+                                              _p(ws), _stream()), "rows_reg_fwd")
+        ctx.save_for_backward(coef, *tables, *ids)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        n = ctx.n
+        coef, tables = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n]
+        g = g.contiguous().to(torch.float32)
+        grads, first, out = {}, {}, [None, None]
+        for t, E in enumerate(tables):
+            if E.data_ptr() not in grads:
+                grads[E.data_ptr()], first[E.data_ptr()] = torch.zeros_like(E), t
+        dE = (ctypes.c_void_p * n)(*[grads[E.data_ptr()].data_ptr() for E in tables])
+        _lib.check(lib.mmrec_rows_reg_bwd_f32(ctx.arrays[0], ctx.arrays[1], ctx.arrays[2], n, tables[0].shape[1], _p(coef), _p(g), dE,
+                                              _stream()), "rows_reg_bwd")
+        for t, E in enumerate(tables):
+            out += [grads[E.data_ptr()] if (first[E.data_ptr()] == t and ctx.needs_input_grad[2 + 2 * t]) else None, None]
+        return tuple(out)
+
+
+ROWS_REG_SQUARED, ROWS_REG_NORM = 0, 1
+
+
+def rows_reg(terms, mode, scale=1.0):
+    """The regulariser of a training step over batch rows, fused: scale * sum_t ||E_t[ids_t]||_F^2 (mode ROWS_REG_SQUARED: the L2
+    regulariser of layergcn.py:154-161 / lattice.py:214-216) or scale * sum_t ||E_t[ids_t]||_F (ROWS_REG_NORM: EmbLoss,
+    common/loss.py:46-51).  terms = [(table [n, 64 k], ids [B]) ...].  Two launches forward, one backward, whatever the number
+    of terms; `hip_deterministic`, more than MMREC_ROWS_REG_MAX_TERMS terms or tables that are views of one another's storage
+    take the per-term ops."""
+    terms = list(terms)
+    same_rows = len({E.shape[1] for E, _ in terms}) == 1
+    if DETERMINISTIC or len(terms) > 6 or not terms or not same_rows or any(not E.is_contiguous() for E, _ in terms):
+        total = 0.0
+        for E, ids in terms:
+            s = gather_sqnorm(E, ids)
+            total = total + (s if mode == ROWS_REG_SQUARED else torch.sqrt(s))
+        return scale * total
+    flat = [x for E, ids in terms for x in (E, ids.contiguous())]
+    return _RowsReg.apply(mode, scale, *flat)
+
+
 class _CosineMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, ix, Y, iy):

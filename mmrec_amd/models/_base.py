@@ -288,10 +288,7 @@ class AdjacentTablesMixin:
                 off += p.shape[0]
 
 
-def emb_loss_rows(tables_and_ids, denom):
-    """EmbLoss over gathered rows: sum_t ||T[ids]||_F / denom (common/loss.py:46-51) on the fused
-    gather-norm kernel."""
-    total = 0.0
-    for table, ids in tables_and_ids:
-        total = total + torch.sqrt(hip_ops.gather_sqnorm(table, ids))
-    return total / denom
+def emb_loss_rows(tables_and_ids, denom, weight=1.0):
+    """weight * EmbLoss over gathered rows: weight * sum_t ||T[ids]||_F / denom (common/loss.py:46-51; `weight` = the model's
+    reg_weight, folded into the kernel's scale) -- every term in one launch pair (hip_ops.rows_reg, ABI 14)."""
+    return hip_ops.rows_reg(tables_and_ids, hip_ops.ROWS_REG_NORM, float(weight) / denom)     # (all terms in one launch pair, ABI 14)

@@ -37,5 +37,4 @@ class BPR(FusedEvalMixin, GeneralRecommender):
         user, pos, neg = interaction[0], interaction[1], interaction[2]
         ue, ie = self.forward()
         mf_loss = hip_ops.bpr_loss(ue, ie, user, pos, neg, hip_ops.BPR_GAMMA, 'mean')
-        reg_loss = emb_loss_rows(((ue, user), (ie, pos), (ie, neg)), neg.shape[0])
-        return mf_loss + self.reg_weight * reg_loss
+        return mf_loss + emb_loss_rows(((ue, user), (ie, pos), (ie, neg)), neg.shape[0], self.reg_weight)

@@ -215,6 +215,6 @@ class LATTICE(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
         self.build_item_graph = False
         ua, ia = ua.contiguous(), ia.contiguous()
         mf_loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
-        reg = 0.5 * (hip_ops.gather_sqnorm(ua, users) + hip_ops.gather_sqnorm(ia, pos_items) +
-                     hip_ops.gather_sqnorm(ia, neg_items)) / self.batch_size
-        return mf_loss + self.reg_weight * reg
+        reg = hip_ops.rows_reg(((ua, users), (ia, pos_items), (ia, neg_items)), hip_ops.ROWS_REG_SQUARED,
+                               0.5 * self.reg_weight / self.batch_size)
+        return mf_loss + reg

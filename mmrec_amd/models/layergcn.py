@@ -84,7 +84,7 @@ class LayerGCN(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralR
         self.forward_adj = self.masked_adj
         u_all, i_all = self.forward()
         mf_loss, = hip_ops.bpr_losses_shared_users(u_all, user, [(i_all, pos, neg)], hip_ops.BPR_LOGSIG, 'sum', joint_grad=True)
-        reg_loss = 0.5 * (hip_ops.gather_sqnorm(self.user_embeddings, user) +
-                          hip_ops.gather_sqnorm(self.item_embeddings, pos) +
-                          hip_ops.gather_sqnorm(self.item_embeddings, neg))
-        return mf_loss + self.reg_weight * reg_loss
+        # 0.5 * (||u||^2 + ||p||^2 + ||n||^2) * reg_weight over the batch's EGO rows (layergcn.py:154-161), one launch pair
+        reg = hip_ops.rows_reg(((self.user_embeddings, user), (self.item_embeddings, pos), (self.item_embeddings, neg)),
+                               hip_ops.ROWS_REG_SQUARED, 0.5 * self.reg_weight)
+        return mf_loss + reg

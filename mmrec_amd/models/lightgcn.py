@@ -51,5 +51,4 @@ class LightGCN(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralR
         u_all, i_all = self.forward()
         mf_loss = hip_ops.bpr_loss(u_all, i_all, user, pos, neg, hip_ops.BPR_GAMMA, 'mean')
         ue, ie = self.embedding_dict['user_emb'], self.embedding_dict['item_emb']
-        reg_loss = emb_loss_rows(((ue, user), (ie, pos), (ie, neg)), user.shape[0])
-        return mf_loss + self.reg_weight * reg_loss
+        return mf_loss + emb_loss_rows(((ue, user), (ie, pos), (ie, neg)), user.shape[0], self.reg_weight)

@@ -167,8 +167,7 @@ class SMORE(FusedEvalMixin, GeneralRecommender):
         ua, ia, side, content = self.forward(self.norm_adj, train=True)
         ua, ia = ua.contiguous(), ia.contiguous()
         mf_loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
-        reg = 0.5 * (hip_ops.gather_sqnorm(ua, users) + hip_ops.gather_sqnorm(ia, pos_items) +
-                     hip_ops.gather_sqnorm(ia, neg_items)) / self.batch_size
+        reg = hip_ops.rows_reg(((ua, users), (ia, pos_items), (ia, neg_items)), hip_ops.ROWS_REG_SQUARED, 0.5 / self.batch_size)
         nu = self.n_users
         cl = hip_ops.infonce(side[nu:].contiguous(), content[nu:].contiguous(), pos_items, 0.2) + \
             hip_ops.infonce(side[:nu].contiguous(), content[:nu].contiguous(), users, 0.2)

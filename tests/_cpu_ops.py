@@ -228,6 +228,15 @@ def gather_sqnorm(E, ids):
     return (E[ids] ** 2).sum()
 
 
+def rows_reg(terms, mode, scale=1.0):
+    """hip_ops.rows_reg (ABI 14): scale * sum_t ||E_t[ids_t]||_F^2 (mode 0) or scale * sum_t ||E_t[ids_t]||_F (mode 1)"""
+    total = 0.0
+    for E, ids in terms:
+        s = gather_sqnorm(E, ids)
+        total = total + (s if mode == 0 else torch.sqrt(s))
+    return scale * total
+
+
 def linear(X, W, b=None):
     _mat(X, "X"), _mat(W, "W")
     assert W.shape[1] == X.shape[1]
@@ -324,7 +333,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "cosine_mean", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "rows_reg", "cosine_mean", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

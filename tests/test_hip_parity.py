@@ -767,6 +767,38 @@ def test_gather_sqnorm(ops, dev):
     close(Ed.grad, E.grad, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rows_reg_fused_regulariser(ops, dev, mode):
+    """ABI 14 mmrec_rows_reg_fwd_f32 / _bwd_f32 (hip_ops.rows_reg): the three terms of a step's regulariser in one launch pair --
+    scale * sum_t ||E_t[ids_t]||_F^2 (mode 0: layergcn.py:154-161) or scale * sum_t ||E_t[ids_t]||_F (mode 1: EmbLoss,
+    common/loss.py:46-51) -- against torch: value and gradients, the item table named by two terms (one dense gradient), duplicate
+    ids, batches of different lengths that are no multiple of 16, 128-wide rows, an upstream gradient != 1, and (mode 1) a term
+    whose rows are all zero: gradient 0 there, as torch.norm's backward gives.  Equal to the per-term ops it replaces."""
+    g = torch.Generator().manual_seed(6 + mode)
+    for d in (64, 128):
+        U, I, Z = (torch.randn(50, d, generator=g).requires_grad_(), torch.randn(70, d, generator=g).requires_grad_(),
+                   torch.zeros(9, d, requires_grad=True))
+        iu, ip, in_, iz = (torch.randint(0, 50, (101,), generator=g), torch.randint(0, 70, (101,), generator=g),
+                           torch.randint(0, 70, (37,), generator=g), torch.randint(0, 9, (5,), generator=g))
+        ip[:20] = ip[20:40]
+        scale = 0.37
+        terms = [(U, iu), (I, ip), (I, in_), (Z, iz)]
+        f = (lambda x: x) if mode == 0 else torch.sqrt
+        ref = scale * sum(f((E[i] ** 2).sum()) for E, i in terms[:3]) + scale * (Z[iz] ** 2).sum() * (1.0 if mode == 0 else 0.0)
+        (1.7 * ref).backward()
+        dev_t = [t.detach().to(dev).requires_grad_() for t in (U, I, Z)]
+        d_terms = [(dev_t[0], iu.to(dev)), (dev_t[1], ip.to(dev)), (dev_t[1], in_.to(dev)), (dev_t[2], iz.to(dev))]
+        out = ops.rows_reg(d_terms, mode, scale)
+        (1.7 * out).backward()
+        close(out, ref, rtol=2e-6)
+        close(dev_t[0].grad, U.grad, rtol=1e-5, atol=1e-7)
+        close(dev_t[1].grad, I.grad, rtol=1e-5, atol=1e-7)
+        assert float(dev_t[2].grad.abs().max()) == 0.0 and torch.isfinite(dev_t[2].grad).all()
+        # the per-term ops it replaces
+        per = scale * sum((lambda x: x if mode == 0 else torch.sqrt(x))(ops.gather_sqnorm(E.detach(), i)) for E, i in d_terms[:3])
+        close(out, per, rtol=2e-6)
+
+
 def test_infonce_fwd_bwd_vs_oracle(ops, dev):
     """In-batch InfoNCE incl. duplicate ids (scatter-add), batch not a multiple of the 64-row tile,
     a zero row (normalisation eps) and asymmetric views."""
