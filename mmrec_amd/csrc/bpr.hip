@@ -197,29 +197,40 @@ __global__ __launch_bounds__(256) void rows_reg_sq_kernel(const RegTerms a, int 
 
 __global__ __launch_bounds__(256) void rows_reg_finish_kernel(const RegTerms a, const float* __restrict__ sq, int mode, float scale,
                                                               float* __restrict__ out, float* __restrict__ coef) {
-    __shared__ float red[256];
-    float total = 0.f;
-    for (int t = 0; t < a.n_terms; ++t) {
-        float x = 0.f;
-        for (int i = threadIdx.x; i < a.batch[t]; i += 256) x += sq[(size_t)t * a.max_batch + i];
-        red[threadIdx.x] = x;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-        const float S = red[0];
-        __syncthreads();
-        if (mode == 0) {
-            total += S;
-            if (threadIdx.x == 0) coef[t] = 2.f * scale;
-        } else {
-            const float nrm = sqrtf(S);
-            total += nrm;
-            if (threadIdx.x == 0) coef[t] = S > 0.f ? scale / nrm : 0.f;
+    // every term summed by the whole workgroup in a fixed order (strided partial sums, wave butterflies, the four waves in
+    // order); the terms' reductions are independent, so their loads are all issued before the first barrier
+    __shared__ float red[MMREC_ROWS_REG_MAX_TERMS][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float x[MMREC_ROWS_REG_MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < MMREC_ROWS_REG_MAX_TERMS; ++t) {
+        x[t] = 0.f;
+        if (t < a.n_terms)
+            for (int i = threadIdx.x; i < a.batch[t]; i += 256) x[t] += sq[(size_t)t * a.max_batch + i];
+    }
+#pragma unroll
+    for (int t = 0; t < MMREC_ROWS_REG_MAX_TERMS; ++t) {
+        if (t < a.n_terms) {
+            const float w = wave_sum(x[t]);
+            if (lane == 0) red[t][wave] = w;
         }
     }
-    if (threadIdx.x == 0) out[0] = scale * total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int t = 0; t < a.n_terms; ++t) {
+            const float S = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+            if (mode == 0) {
+                total += S;
+                coef[t] = 2.f * scale;
+            } else {
+                const float nrm = sqrtf(S);
+                total += nrm;
+                coef[t] = S > 0.f ? scale / nrm : 0.f;
+            }
+        }
+        out[0] = scale * total;
+    }
 }
 
 __global__ __launch_bounds__(256) void rows_reg_bwd_kernel(const RegTerms a, int d4, const float* __restrict__ coef,
