@@ -202,6 +202,15 @@ int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* const* ids, con
 int mmrec_rows_reg_bwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms, int32_t d,
                            const float* coef, const float* g, float* const* dE, mmrec_stream_t stream);
 
+/* ABI 14 -- the elementwise tail of an MMGCN layer (mmgcn.py:170-173, :176-179, :182-185) in one launch each way:
+ *   fwd: out [n, wa + wb] = [ leaky_relu(A [n, wa]) | leaky_relu(B [n, wb]) + R [n, wb] ]   (R may be NULL; wa, wb % 4 == 0)
+ *   bwd: dA = dOut[:, :wa] * (A > 0 ? 1 : slope), dB likewise from dOut[:, wa:], dR = dOut[:, wa:] (each may be NULL)
+ * replaces: F.leaky_relu x 2, the `+ id_embedding`, torch.cat((h, x_hat), dim=1) and their four backward launches. */
+int mmrec_cat_leaky_fwd_f32(const float* A, const float* B, const float* R, int64_t n, int32_t wa, int32_t wb, float slope,
+                            float* out, mmrec_stream_t stream);
+int mmrec_cat_leaky_bwd_f32(const float* A, const float* B, const float* dOut, int64_t n, int32_t wa, int32_t wb, float slope,
+                            float* dA, float* dB, float* dR, mmrec_stream_t stream);
+
 
 /* In-batch InfoNCE between two views of the same ids (d = 64), logits never materialised:
  *   v1 = normalize(E1[ids]), v2 = normalize(E2[ids])  (F.normalize, eps 1e-12)

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libmmrec_hip.so")
-SOURCES = ["api.hip", "spmm.hip", "spmm_narrow.hip", "bpr.hip", "infonce.hip", "gemm.hip", "topk.hip", "topk_filter.hip", "graph.hip", "evalsample.hip", "adam.hip"]
+SOURCES = ["api.hip", "spmm.hip", "spmm_narrow.hip", "bpr.hip", "infonce.hip", "gemm.hip", "topk.hip", "topk_filter.hip", "graph.hip", "evalsample.hip", "adam.hip", "layer_ew.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 EXTRA_FLAGS = {}    # per-file extras: {source name: [flags]}

@@ -1036,6 +1036,40 @@ def rows_reg(terms, mode, scale=1.0):
     return _RowsReg.apply(mode, scale, *flat)
 
 
+class _CatLeaky(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, R, slope):
+        lib = _lib.load()
+        A, B = _chk(A.contiguous(), torch.float32, "A", 2), _chk(B.contiguous(), torch.float32, "B", 2)
+        if R is not None:
+            R = _chk(R.contiguous(), torch.float32, "R", 2)
+        n, wa, wb = A.shape[0], A.shape[1], B.shape[1]
+        if B.shape[0] != n or (R is not None and R.shape != B.shape) or wa % 4 or wb % 4:
+            raise _lib.MMRecHipError("cat_leaky: A [n, wa], B [n, wb], R [n, wb] with wa, wb multiples of 4")
+        out = torch.empty(n, wa + wb, dtype=torch.float32, device=A.device)
+        _lib.check(lib.mmrec_cat_leaky_fwd_f32(_p(A), _p(B), _p(R), n, wa, wb, float(slope), _p(out), _stream()), "cat_leaky_fwd")
+        ctx.save_for_backward(A, B)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        A, B = ctx.saved_tensors
+        dOut = dOut.contiguous()
+        dA = torch.empty_like(A) if ctx.needs_input_grad[0] else None
+        dB = torch.empty_like(B) if ctx.needs_input_grad[1] else None
+        dR = torch.empty_like(B) if ctx.needs_input_grad[2] else None
+        _lib.check(lib.mmrec_cat_leaky_bwd_f32(_p(A), _p(B), _p(dOut), A.shape[0], A.shape[1], B.shape[1], ctx.slope, _p(dA), _p(dB),
+                                               _p(dR), _stream()), "cat_leaky_bwd")
+        return dA, dB, dR, None
+
+
+def cat_leaky(A, B, R=None, slope=0.01):
+    """cat((leaky_relu(A), leaky_relu(B) + R), dim=1) in one launch each way (mmgcn.py:170-173: h, x_hat and their cat)."""
+    return _CatLeaky.apply(A, B, R, slope)
+
+
 class _CosineMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, ix, Y, iy):

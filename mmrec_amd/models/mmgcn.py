@@ -91,9 +91,8 @@ class GCN(nn.Module):
                               (self.conv_embed_3, self.linear_layer3, self.g_layer3)):
             # every 64-wide layer runs on the MFMA projection kernels (forward, dW + db, dX): the
             # library's skinny dW GEMMs (contraction over 26k nodes) were 47 % of the step
-            h = F.leaky_relu(conv(x, graph))
-            x_hat = F.leaky_relu(_lin64(lin, x)) + id_embedding
-            x = F.leaky_relu(_lin64(gl, torch.cat((h, x_hat), dim=1)))
+            # h = leaky_relu(conv(x)), x_hat = leaky_relu(linear(x)) + id_embedding and their cat (mmgcn.py:170-173): one launch
+            x = F.leaky_relu(_lin64(gl, hip_ops.cat_leaky(conv(x, graph), _lin64(lin, x), id_embedding)))
         return x
 
 

@@ -228,6 +228,12 @@ def gather_sqnorm(E, ids):
     return (E[ids] ** 2).sum()
 
 
+def cat_leaky(A, B, R=None, slope=0.01):
+    """hip_ops.cat_leaky: cat((leaky_relu(A), leaky_relu(B) + R), dim=1)"""
+    x_hat = F.leaky_relu(B, slope)
+    return torch.cat((F.leaky_relu(A, slope), x_hat if R is None else x_hat + R), dim=1)
+
+
 def rows_reg(terms, mode, scale=1.0):
     """hip_ops.rows_reg (ABI 14): scale * sum_t ||E_t[ids_t]||_F^2 (mode 0) or scale * sum_t ||E_t[ids_t]||_F (mode 1)"""
     total = 0.0
@@ -333,7 +339,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "rows_reg", "cosine_mean", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "rows_reg", "cat_leaky", "cosine_mean", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

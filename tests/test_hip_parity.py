@@ -799,6 +799,34 @@ def test_rows_reg_fused_regulariser(ops, dev, mode):
         close(out, per, rtol=2e-6)
 
 
+@pytest.mark.parametrize("n,wa,wb,with_r", [(300, 64, 64, True), (1001, 384, 64, True), (77, 256, 64, False), (5, 4, 8, True)])
+def test_cat_leaky_fused_layer_tail(ops, dev, n, wa, wb, with_r):
+    """ABI 14 mmrec_cat_leaky_fwd/bwd_f32 (hip_ops.cat_leaky): cat((leaky_relu(A), leaky_relu(B) + R), dim=1) of an MMGCN layer
+    (mmgcn.py:170-173) == the four torch ops, values and gradients BIT FOR BIT (elementwise: nothing to reorder), exact zeros and
+    negative inputs included, R absent / without gradient."""
+    g = torch.Generator().manual_seed(n + wa)
+    A, B = torch.randn(n, wa, generator=g), torch.randn(n, wb, generator=g)
+    A[0, :4] = 0.0
+    B[n - 1] = 0.0
+    R = torch.randn(n, wb, generator=g) if with_r else None
+    G = torch.randn(n, wa + wb, generator=g)
+    a, b = A.clone().requires_grad_(), B.clone().requires_grad_()
+    r = R.clone().requires_grad_() if with_r else None
+    x_hat = torch.nn.functional.leaky_relu(b)
+    ref = torch.cat((torch.nn.functional.leaky_relu(a), x_hat + r if with_r else x_hat), dim=1)
+    ref.backward(G)
+    ad, bd = A.to(dev).requires_grad_(), B.to(dev).requires_grad_()
+    rd = R.to(dev).requires_grad_() if with_r else None
+    out = ops.cat_leaky(ad, bd, rd)
+    out.backward(G.to(dev))
+    assert torch.equal(out.cpu(), ref.detach())
+    assert torch.equal(ad.grad.cpu(), a.grad) and torch.equal(bd.grad.cpu(), b.grad)
+    if with_r:
+        assert torch.equal(rd.grad.cpu(), r.grad)
+        out2 = ops.cat_leaky(A.to(dev).requires_grad_(), B.to(dev), R.to(dev))       # R, B without gradient
+        out2.sum().backward()
+
+
 def test_infonce_fwd_bwd_vs_oracle(ops, dev):
     """In-batch InfoNCE incl. duplicate ids (scatter-add), batch not a multiple of the 64-row tile,
     a zero row (normalisation eps) and asymmetric views."""
