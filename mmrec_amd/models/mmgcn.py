@@ -49,11 +49,20 @@ class _Conv(nn.Module):
         return hip_ops.spmm(graph, torch.matmul(x, self.weight))
 
 
+SLICED_WIDE_MLP = True
+
+
 def _lin64(layer, x):
     """nn.Linear with 64 outputs and an input width that is a multiple of 4 -> hip_ops.linear."""
     if layer.out_features == hip_ops.EMB_DIM and layer.in_features % 4 == 0:
         return hip_ops.linear(x.contiguous(), layer.weight, layer.bias)
     if layer.out_features % 64 == 0 and layer.in_features % 32 == 0:      # the 4096 -> 256 MLP
+        if SLICED_WIDE_MLP and layer.in_features >= hip_ops.LINEAR_SPLIT_MIN_F and hip_ops.LINEAR_F16X3:
+            # 64 outputs at a time on the split-operand kernels (X streamed four times at 23 us each) instead of the 128 x 128
+            # fp32-MFMA GEMM, which fills 112 of 256 CUs at 7,050 x 256 outputs (287 us)
+            x = x.contiguous()
+            return torch.cat([hip_ops.linear(x, layer.weight[z:z + 64], None if layer.bias is None else layer.bias[z:z + 64])
+                              for z in range(0, layer.out_features, 64)], dim=1)
         return hip_ops.linear(x.contiguous(), layer.weight, layer.bias)
     return layer(x)
 
