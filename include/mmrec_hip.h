@@ -192,7 +192,8 @@ int mmrec_gather_scale_add_bwd_f32(const float* E, const int64_t* ids, int32_t b
  *   vbpr.py:95, lightgcn.py:145-149); n_terms <= MMREC_ROWS_REG_MAX_TERMS, batch[t] rows per term, rows of d = 64 k floats.
  *   coef[t] (out, device) = the factor of the backward: dE[t][ids[t][b]] += g[0] * coef[t] * E[t][ids[t][b]] (fp32 atomics;
  *   two terms may name the same E / dE: the item table's positive and negative rows).  A term whose S_t is 0 gets coef 0 in
- *   mode 1, as torch.norm's backward does.  E, ids, batch, dE are HOST arrays of n_terms entries (copied into the launch).
+ *   mode 1, as torch.norm's backward does.  ids[t] NULL: rows 0 .. batch[t] - 1 of E[t] (a whole table: bm3.py:146's
+ *   EmbLoss(u, i)).  E, ids, batch, dE are HOST arrays of n_terms entries (copied into the launch).
  * replaces: the per-term mmrec_gather_sqnorm_fwd_f32 / mmrec_gather_scale_add_bwd_f32 calls and the ~20 elementwise
  * launches between them (a quarter of a LayerGCN / VBPR step at Amazon-Baby size). */
 #define MMREC_ROWS_REG_MAX_TERMS 6
@@ -201,6 +202,21 @@ int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* const* ids, con
                            int32_t mode, float scale, float* out, float* coef, void* workspace, mmrec_stream_t stream);
 int mmrec_rows_reg_bwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms, int32_t d,
                            const float* coef, const float* g, float* const* dE, mmrec_stream_t stream);
+
+/* ABI 14 -- several mean-cosine terms in one forward call (two launches) and one backward launch:
+ *   out[0] = sum_t w[t] * mean_b cos(X[t][ix[t][b]], Y[t][iy[t][b]])   (ix[t] / iy[t] NULL: row b; Y constant; F.cosine_similarity's
+ *   1e-8 clamp; n_terms <= MMREC_COSINE_MAX_TERMS, rows of d = 64 k floats), coef [n_terms][max_batch][2] as mmrec_cosine_fwd_f32's;
+ *   bwd: dX[t][ix[t][b]] += g[0] w[t] / batch[t] (coef.x y - coef.y x) by fp32 atomics (dX[t] NULL: no gradient for that term;
+ *   terms may share X / dX).  X, ix, Y, iy, w, batch, dX are HOST arrays of n_terms entries.
+ * replaces: the six `1 - cosine_similarity(...).mean()` terms of bm3.py:129-144 (per-term form: mmrec_cosine_fwd/bwd_f32). */
+#define MMREC_COSINE_MAX_TERMS 8
+size_t mmrec_cosine_multi_workspace_bytes(int32_t n_terms, int32_t max_batch);
+int mmrec_cosine_multi_fwd_f32(const float* const* X, const int64_t* const* ix, const float* const* Y, const int64_t* const* iy,
+                               const float* w, const int32_t* batch, int32_t n_terms, int32_t d, float* out, float* coef,
+                               void* workspace, mmrec_stream_t stream);
+int mmrec_cosine_multi_bwd_f32(const float* const* X, const int64_t* const* ix, const float* const* Y, const int64_t* const* iy,
+                               const float* w, const int32_t* batch, int32_t n_terms, int32_t d, const float* coef,
+                               const float* grad_scalar, float* const* dX, mmrec_stream_t stream);
 
 /* ABI 14 -- the elementwise tail of an MMGCN layer (mmgcn.py:170-173, :176-179, :182-185) in one launch each way:
  *   fwd: out [n, wa + wb] = [ leaky_relu(A [n, wa]) | leaky_relu(B [n, wb]) + R [n, wb] ]   (R may be NULL; wa, wb % 4 == 0)

@@ -165,6 +165,102 @@ __global__ __launch_bounds__(256) void gather_scale_add_kernel(const float* __re
     }
 }
 
+// ---- several mean-cosine terms in one launch pair (ABI 14): BM3's six BYOL terms (bm3.py:129-144) ---------------------------------
+// out = sum_t w_t mean_b cos(X_t[ix_t[b]], Y_t[iy_t[b]]) with cosine_fwd_kernel's arithmetic per row; the per-term calls were
+// 6 x (rows, sum) launches forward and 6 backward plus ~25 elementwise launches for the `1 - .` / weights / sums around them,
+// a sixth of a BM3 step at Amazon-Clothing size.  Backward: dX_t[ix_t[b]] += g w_t / B_t (coef.x y - coef.y x), all terms in
+// one launch; terms that share X share its gradient buffer.
+struct CosTerms {
+    const float* X[MMREC_COSINE_MAX_TERMS];
+    const float* Y[MMREC_COSINE_MAX_TERMS];
+    const int64_t* ix[MMREC_COSINE_MAX_TERMS];
+    const int64_t* iy[MMREC_COSINE_MAX_TERMS];
+    float* dX[MMREC_COSINE_MAX_TERMS];
+    float w[MMREC_COSINE_MAX_TERMS];
+    int batch[MMREC_COSINE_MAX_TERMS];
+    int n_terms, max_batch;
+};
+
+__global__ __launch_bounds__(256) void cosine_multi_fwd_kernel(const CosTerms a, int d4, float* __restrict__ cos_i,
+                                                               float2* __restrict__ coef) {
+    __shared__ float s_row[16];
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if ((int)blockIdx.x * 16 >= a.batch[t]) return;     // (uniform)
+    float xy = 0.f, xx = 0.f, yy = 0.f;
+    if (b < a.batch[t]) {
+        const size_t rx = (size_t)(a.ix[t] ? a.ix[t][b] : b) * d4, ry = (size_t)(a.iy[t] ? a.iy[t][b] : b) * d4;
+        for (int c = lane16; c < d4; c += 16) {
+            const float4 x = reinterpret_cast<const float4*>(a.X[t])[rx + c];
+            const float4 y = reinterpret_cast<const float4*>(a.Y[t])[ry + c];
+            xy += f4_dot(x, y);
+            xx += f4_dot(x, x);
+            yy += f4_dot(y, y);
+        }
+    }
+    xy = row16_sum(xy);
+    xx = row16_sum(xx);
+    yy = row16_sum(yy);
+    if (lane16 == 0 && b < a.batch[t]) {
+        const float nx = sqrtf(xx), ny = sqrtf(yy);
+        const float cx = fmaxf(nx, 1e-8f), cy = fmaxf(ny, 1e-8f);
+        const float inv = 1.0f / (cx * cy), cs = xy * inv;
+        coef[(size_t)t * a.max_batch + b] = make_float2(inv, nx > 1e-8f ? cs / (cx * cx) : 0.f);
+        s_row[threadIdx.x >> 4] = cs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                              // the block's 16 cosines in row order: one value per workgroup
+        float tot = 0.f;
+        const int live = min(16, a.batch[t] - (int)blockIdx.x * 16);
+        for (int i = 0; i < live; ++i) tot += s_row[i];
+        cos_i[(size_t)t * ((a.max_batch + 15) / 16) + blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void cosine_multi_finish_kernel(const CosTerms a, const float* __restrict__ cos_i,
+                                                                  float* __restrict__ out) {
+    __shared__ float red[MMREC_COSINE_MAX_TERMS][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float x[MMREC_COSINE_MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < MMREC_COSINE_MAX_TERMS; ++t) {
+        x[t] = 0.f;
+        if (t < a.n_terms)
+            for (int i = threadIdx.x; i < (a.batch[t] + 15) / 16; i += 256) x[t] += cos_i[(size_t)t * ((a.max_batch + 15) / 16) + i];
+    }
+#pragma unroll
+    for (int t = 0; t < MMREC_COSINE_MAX_TERMS; ++t) {
+        if (t < a.n_terms) {
+            const float w = wave_sum(x[t]);
+            if (lane == 0) red[t][wave] = w;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int t = 0; t < a.n_terms; ++t)
+            total += a.w[t] * (((red[t][0] + red[t][1]) + (red[t][2] + red[t][3])) / (float)max(a.batch[t], 1));
+        out[0] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void cosine_multi_bwd_kernel(const CosTerms a, int d4, const float2* __restrict__ coef,
+                                                               const float* __restrict__ grad_scalar) {
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= a.batch[t] || !a.dX[t]) return;
+    const size_t rx = (size_t)(a.ix[t] ? a.ix[t][b] : b) * d4, ry = (size_t)(a.iy[t] ? a.iy[t][b] : b) * d4;
+    const float g = grad_scalar[0] * a.w[t] / (float)a.batch[t];
+    const float2 cf = coef[(size_t)t * a.max_batch + b];
+    const float ca = g * cf.x, cc = g * cf.y;
+    for (int k = lane16; k < d4; k += 16) {
+        const float4 x = reinterpret_cast<const float4*>(a.X[t])[rx + k];
+        const float4 y = reinterpret_cast<const float4*>(a.Y[t])[ry + k];
+        atomic_add_f4(a.dX[t] + (rx + k) * 4, make_float4(ca * y.x - cc * x.x, ca * y.y - cc * x.y, ca * y.z - cc * x.z,
+                                                          ca * y.w - cc * x.w));
+    }
+}
+
 // ---- the regulariser of a training step in ONE forward and ONE backward launch pair (ABI 14) --------------------------------
 // reg = scale * sum_t f(S_t),  S_t = sum_b ||E_t[ids_t[b]]||^2,  f = identity (mode 0: the L2 regulariser on batch rows,
 // layergcn.py:154-161, lattice.py:214-216) or sqrt (mode 1: EmbLoss, common/loss.py:46-51 as used at vbpr.py:95,
@@ -178,21 +274,34 @@ struct RegTerms {
     const int64_t* ids[MMREC_ROWS_REG_MAX_TERMS];
     float* dE[MMREC_ROWS_REG_MAX_TERMS];
     int batch[MMREC_ROWS_REG_MAX_TERMS];
-    int n_terms, max_batch;
+    int exclusive[MMREC_ROWS_REG_MAX_TERMS];   // no other term writes this term's dE
+    int n_terms, max_batch, max_blocks;
 };
 
 __global__ __launch_bounds__(256) void rows_reg_sq_kernel(const RegTerms a, int d4, float* __restrict__ sq) {
-    const int t = blockIdx.y, lane16 = threadIdx.x & 15;
-    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (b >= a.batch[t]) return;
-    const float4* row = reinterpret_cast<const float4*>(a.E[t]) + (size_t)a.ids[t][b] * d4;
+    // sq[t][block] = the squared norms of the block's 16 rows, summed in row order (one value per workgroup: a whole table as a
+    // term -- 39,387 rows at Amazon-Clothing size -- left the one-workgroup finish 57 us of sums)
+    __shared__ float s_row[16];
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int b = blockIdx.x * 16 + g;
+    if (blockIdx.x * 16 >= a.batch[t]) return;          // (uniform)
     float x = 0.f;
-    for (int k = lane16; k < d4; k += 16) {
-        const float4 e = row[k];
-        x += f4_dot(e, e);
+    if (b < a.batch[t]) {
+        const float4* row = reinterpret_cast<const float4*>(a.E[t]) + (size_t)(a.ids[t] ? a.ids[t][b] : b) * d4;     // ids NULL: every row
+        for (int k = lane16; k < d4; k += 16) {
+            const float4 e = row[k];
+            x += f4_dot(e, e);
+        }
     }
     const float s = row16_sum(x);
-    if (lane16 == 0) sq[(size_t)t * a.max_batch + b] = s;
+    if (lane16 == 0) s_row[g] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += s_row[i];
+        sq[(size_t)t * a.max_blocks + blockIdx.x] = tot;
+    }
 }
 
 __global__ __launch_bounds__(256) void rows_reg_finish_kernel(const RegTerms a, const float* __restrict__ sq, int mode, float scale,
@@ -206,7 +315,7 @@ __global__ __launch_bounds__(256) void rows_reg_finish_kernel(const RegTerms a, 
     for (int t = 0; t < MMREC_ROWS_REG_MAX_TERMS; ++t) {
         x[t] = 0.f;
         if (t < a.n_terms)
-            for (int i = threadIdx.x; i < a.batch[t]; i += 256) x[t] += sq[(size_t)t * a.max_batch + i];
+            for (int i = threadIdx.x; i < (a.batch[t] + 15) / 16; i += 256) x[t] += sq[(size_t)t * a.max_blocks + i];
     }
 #pragma unroll
     for (int t = 0; t < MMREC_ROWS_REG_MAX_TERMS; ++t) {
@@ -239,9 +348,12 @@ __global__ __launch_bounds__(256) void rows_reg_bwd_kernel(const RegTerms a, int
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (b >= a.batch[t]) return;
     const float c = g[0] * coef[t];
+    const bool store = a.ids[t] == nullptr && a.exclusive[t];      // a whole table named by this term only: every element once
     for (int k = lane16; k < d4; k += 16) {
-        const size_t i = (size_t)a.ids[t][b] * d4 + k;
-        atomic_add_f4(a.dE[t] + i * 4, f4_scale(c, reinterpret_cast<const float4*>(a.E[t])[i]));
+        const size_t i = (size_t)(a.ids[t] ? a.ids[t][b] : b) * d4 + k;
+        const float4 v = f4_scale(c, reinterpret_cast<const float4*>(a.E[t])[i]);
+        if (store) reinterpret_cast<float4*>(a.dE[t])[i] = v;
+        else atomic_add_f4(a.dE[t] + i * 4, v);
     }
 }
 
@@ -423,21 +535,76 @@ extern "C" int mmrec_gather_scale_add_bwd_f32(const float* E, const int64_t* ids
 }
 
 namespace {
-int reg_terms(RegTerms& a, const float* const* E, const int64_t* const* ids, float* const* dE, const int32_t* batch,
-              int32_t n_terms) {
-    if (n_terms < 1 || n_terms > MMREC_ROWS_REG_MAX_TERMS || !E || !ids || !batch) return MMREC_ERR_BAD_ARG;
+int cos_terms(CosTerms& a, const float* const* X, const int64_t* const* ix, const float* const* Y, const int64_t* const* iy,
+              const float* w, float* const* dX, const int32_t* batch, int32_t n_terms) {
+    if (n_terms < 1 || n_terms > MMREC_COSINE_MAX_TERMS || !X || !Y || !ix || !iy || !w || !batch) return MMREC_ERR_BAD_ARG;
     a.n_terms = n_terms, a.max_batch = 0;
     for (int t = 0; t < n_terms; ++t) {
-        if (batch[t] < 0 || (batch[t] > 0 && (!E[t] || !ids[t] || (dE && !dE[t])))) return MMREC_ERR_BAD_ARG;
-        a.E[t] = E[t], a.ids[t] = ids[t], a.dE[t] = dE ? dE[t] : nullptr, a.batch[t] = batch[t];
+        if (batch[t] < 0 || (batch[t] > 0 && (!X[t] || !Y[t]))) return MMREC_ERR_BAD_ARG;
+        a.X[t] = X[t], a.Y[t] = Y[t], a.ix[t] = ix[t], a.iy[t] = iy[t], a.w[t] = w[t], a.dX[t] = dX ? dX[t] : nullptr;
+        a.batch[t] = batch[t];
         if (batch[t] > a.max_batch) a.max_batch = batch[t];
     }
     return 0;
 }
 }  // namespace
 
-extern "C" size_t mmrec_rows_reg_workspace_bytes(int32_t n_terms, int32_t max_batch) {
+extern "C" size_t mmrec_cosine_multi_workspace_bytes(int32_t n_terms, int32_t max_batch) {
     return (size_t)(n_terms > 0 ? n_terms : 0) * (size_t)(max_batch > 0 ? max_batch : 0) * sizeof(float) + 16;
+}
+
+extern "C" int mmrec_cosine_multi_fwd_f32(const float* const* X, const int64_t* const* ix, const float* const* Y,
+                                          const int64_t* const* iy, const float* w, const int32_t* batch, int32_t n_terms, int32_t d,
+                                          float* out, float* coef, void* workspace, mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    CosTerms a;
+    if (int err = cos_terms(a, X, ix, Y, iy, w, nullptr, batch, n_terms)) return err;
+    if (!out || !coef || !workspace) return MMREC_ERR_BAD_ARG;
+    hipStream_t s = mmrec_stream(stream);
+    float* cos_i = static_cast<float*>(workspace);
+    if (a.max_batch > 0)
+        hipLaunchKernelGGL(cosine_multi_fwd_kernel, dim3((a.max_batch + 15) / 16, n_terms), dim3(256), 0, s, a, d / 4, cos_i,
+                           reinterpret_cast<float2*>(coef));
+    hipLaunchKernelGGL(cosine_multi_finish_kernel, dim3(1), dim3(256), 0, s, a, (const float*)cos_i, out);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_cosine_multi_bwd_f32(const float* const* X, const int64_t* const* ix, const float* const* Y,
+                                          const int64_t* const* iy, const float* w, const int32_t* batch, int32_t n_terms, int32_t d,
+                                          const float* coef, const float* grad_scalar, float* const* dX, mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    CosTerms a;
+    if (!dX) return MMREC_ERR_BAD_ARG;
+    if (int err = cos_terms(a, X, ix, Y, iy, w, dX, batch, n_terms)) return err;
+    if (!coef || !grad_scalar) return MMREC_ERR_BAD_ARG;
+    if (a.max_batch == 0) return 0;
+    hipLaunchKernelGGL(cosine_multi_bwd_kernel, dim3((a.max_batch + 15) / 16, n_terms), dim3(256), 0, mmrec_stream(stream), a, d / 4,
+                       reinterpret_cast<const float2*>(coef), grad_scalar);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+namespace {
+int reg_terms(RegTerms& a, const float* const* E, const int64_t* const* ids, float* const* dE, const int32_t* batch,
+              int32_t n_terms) {
+    if (n_terms < 1 || n_terms > MMREC_ROWS_REG_MAX_TERMS || !E || !ids || !batch) return MMREC_ERR_BAD_ARG;
+    a.n_terms = n_terms, a.max_batch = 0;
+    for (int t = 0; t < n_terms; ++t) {
+        if (batch[t] < 0 || (batch[t] > 0 && (!E[t] || (dE && !dE[t])))) return MMREC_ERR_BAD_ARG;      // ids[t] NULL: rows 0 .. batch[t] - 1
+        a.E[t] = E[t], a.ids[t] = ids[t], a.dE[t] = dE ? dE[t] : nullptr, a.batch[t] = batch[t];
+        if (batch[t] > a.max_batch) a.max_batch = batch[t];
+    }
+    a.max_blocks = (a.max_batch + 15) / 16;
+    for (int t = 0; t < n_terms; ++t) {
+        a.exclusive[t] = 1;
+        for (int u = 0; u < n_terms; ++u)
+            if (u != t && dE && dE[u] == dE[t]) a.exclusive[t] = 0;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t mmrec_rows_reg_workspace_bytes(int32_t n_terms, int32_t max_batch) {
+    return (size_t)(n_terms > 0 ? n_terms : 0) * (size_t)((max_batch > 0 ? max_batch : 0) + 15) / 16 * sizeof(float) + 64;
 }
 
 extern "C" int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms,
@@ -451,7 +618,7 @@ extern "C" int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* cons
     hipStream_t s = mmrec_stream(stream);
     float* sq = static_cast<float*>(workspace);
     if (a.max_batch > 0)
-        hipLaunchKernelGGL(rows_reg_sq_kernel, dim3((a.max_batch + 15) / 16, n_terms), dim3(256), 0, s, a, d / 4, sq);
+        hipLaunchKernelGGL(rows_reg_sq_kernel, dim3(a.max_blocks, n_terms), dim3(256), 0, s, a, d / 4, sq);
     hipLaunchKernelGGL(rows_reg_finish_kernel, dim3(1), dim3(256), 0, s, a, (const float*)sq, mode, scale, out, coef);
     MMREC_RETURN_LAUNCH_STATUS();
 }

@@ -982,18 +982,19 @@ class _RowsReg(torch.autograd.Function):
     def forward(ctx, mode, scale, *flat):
         lib = _lib.load()
         tables = [_chk(flat[2 * t].contiguous(), torch.float32, "E", 2) for t in range(len(flat) // 2)]
-        ids = [_chk(flat[2 * t + 1], torch.int64, "ids", 1) for t in range(len(flat) // 2)]
+        ids = [None if flat[2 * t + 1] is None else _chk(flat[2 * t + 1], torch.int64, "ids", 1) for t in range(len(flat) // 2)]
         n, d, dev = len(tables), tables[0].shape[1], tables[0].device
         if any(E.shape[1] != d for E in tables) or d % EMB_DIM:
             raise _lib.MMRecHipError("rows_reg: every table needs the same row width, a multiple of %d" % EMB_DIM)
-        batch = (ctypes.c_int32 * n)(*[i.numel() for i in ids])
-        ctx.arrays = ((ctypes.c_void_p * n)(*[E.data_ptr() for E in tables]), (ctypes.c_void_p * n)(*[i.data_ptr() for i in ids]), batch)
+        batch = (ctypes.c_int32 * n)(*[E.shape[0] if i is None else i.numel() for E, i in zip(tables, ids)])   # ids None: every row
+        ctx.arrays = ((ctypes.c_void_p * n)(*[E.data_ptr() for E in tables]),
+                      (ctypes.c_void_p * n)(*[None if i is None else i.data_ptr() for i in ids]), batch)
         out = torch.empty((), dtype=torch.float32, device=dev)
         coef = torch.empty(n, dtype=torch.float32, device=dev)
         ws = _ws(lib.mmrec_rows_reg_workspace_bytes(n, max(batch)), dev)
         _lib.check(lib.mmrec_rows_reg_fwd_f32(ctx.arrays[0], ctx.arrays[1], batch, n, d, int(mode), float(scale), _p(out), _p(coef),
                                               _p(ws), _stream()), "rows_reg_fwd")
-        ctx.save_for_backward(coef, *tables, *ids)
+        ctx.save_for_backward(coef, *tables, *[i for i in ids if i is not None])     # (the ids: kept alive for the backward's pointers)
         ctx.n = n
         return out
 
@@ -1029,10 +1030,10 @@ def rows_reg(terms, mode, scale=1.0):
     if DETERMINISTIC or len(terms) > 6 or not terms or not same_rows or any(not E.is_contiguous() for E, _ in terms):
         total = 0.0
         for E, ids in terms:
-            s = gather_sqnorm(E, ids)
+            s = (E * E).sum() if ids is None else gather_sqnorm(E, ids)
             total = total + (s if mode == ROWS_REG_SQUARED else torch.sqrt(s))
         return scale * total
-    flat = [x for E, ids in terms for x in (E, ids.contiguous())]
+    flat = [x for E, ids in terms for x in (E, None if ids is None else ids.contiguous())]
     return _RowsReg.apply(mode, scale, *flat)
 
 
@@ -1111,6 +1112,71 @@ class _CosineMean(torch.autograd.Function):
         _lib.check(lib.mmrec_cosine_bwd_f32(_p(X), _p(ix), _p(Y), _p(iy), ctx.B, X.shape[1], _p(coef), _p(g),
                                             1.0 / max(ctx.B, 1), _p(dX), _stream()), "cosine_bwd")
         return dX, None, None, None
+
+
+class _CosineMeans(torch.autograd.Function):
+    """sum_t w_t mean_b cos(X_t[ix_t[b]], Y_t[iy_t[b]]): mmrec_cosine_multi_fwd_f32 / _bwd_f32 (ABI 14).  Inputs: the weights
+    (tuple of floats), then X_0, ix_0, Y_0, iy_0, X_1, ... (indices may be None); terms that share X share its gradient."""
+
+    @staticmethod
+    def forward(ctx, weights, *flat):
+        lib = _lib.load()
+        n = len(weights)
+        X = [_chk(flat[4 * t].contiguous(), torch.float32, "X", 2) for t in range(n)]
+        Y = [_chk(flat[4 * t + 2].contiguous(), torch.float32, "Y", 2) for t in range(n)]
+        ix, iy = [flat[4 * t + 1] for t in range(n)], [flat[4 * t + 3] for t in range(n)]
+        d, dev = X[0].shape[1], X[0].device
+        batch = []
+        for t in range(n):
+            for i, nm in ((ix[t], "ix"), (iy[t], "iy")):
+                if i is not None:
+                    _chk(i, torch.int64, nm, 1)
+            B = ix[t].numel() if ix[t] is not None else (iy[t].numel() if iy[t] is not None else X[t].shape[0])
+            if X[t].shape[1] != d or Y[t].shape[1] != d or d % EMB_DIM:
+                raise _lib.MMRecHipError("cosine_means: every operand needs the same row width, a multiple of %d" % EMB_DIM)
+            if (ix[t] is None and X[t].shape[0] != B) or (iy[t] is None and Y[t].shape[0] != B):
+                raise _lib.MMRecHipError("an operand without an index must have one row per sample")
+            batch.append(B)
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+        ctx.arrays = (ptrs(X), ptrs(ix), ptrs(Y), ptrs(iy), (ctypes.c_float * n)(*[float(w) for w in weights]), (ctypes.c_int32 * n)(*batch))
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(n, max(max(batch), 1), 2, dtype=torch.float32, device=dev)
+        ws = _ws(lib.mmrec_cosine_multi_workspace_bytes(n, max(batch)), dev)
+        _lib.check(lib.mmrec_cosine_multi_fwd_f32(*ctx.arrays, n, d, _p(out), _p(coef), _p(ws), _stream()), "cosine_multi_fwd")
+        ctx.save_for_backward(coef, *X, *Y, *[i for i in ix + iy if i is not None])
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        n = ctx.n
+        coef, X = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n]
+        g = g.contiguous().to(torch.float32)
+        grads, first = {}, {}
+        for t, x in enumerate(X):
+            if ctx.needs_input_grad[1 + 4 * t] and x.data_ptr() not in grads:
+                grads[x.data_ptr()], first[x.data_ptr()] = torch.zeros_like(x), t
+        dX = (ctypes.c_void_p * n)(*[grads[x.data_ptr()].data_ptr() if x.data_ptr() in grads else None for x in X])
+        _lib.check(lib.mmrec_cosine_multi_bwd_f32(*ctx.arrays, n, X[0].shape[1], _p(coef), _p(g), dX, _stream()), "cosine_multi_bwd")
+        out = [None]
+        for t, x in enumerate(X):
+            out += [grads[x.data_ptr()] if first.get(x.data_ptr()) == t else None, None, None, None]
+        return tuple(out)
+
+
+def cosine_means(terms):
+    """sum_t w_t mean_b cosine_similarity(X_t[ix_t[b]], Y_t[iy_t[b]]) for terms = [(X, ix, Y, iy, w), ...] in one launch pair
+    (Y constant, indices may be None): BM3's six BYOL terms (bm3.py:129-144).  `hip_deterministic` or more than
+    MMREC_COSINE_MAX_TERMS terms: the per-term op."""
+    terms = list(terms)
+    if DETERMINISTIC or not terms or len(terms) > 8:
+        total = 0.0
+        for X, ix, Y, iy, w in terms:
+            total = total + w * cosine_mean(X, ix, Y, iy)
+        return total
+    flat = [a for X, ix, Y, iy, _ in terms for a in (X, ix, Y.detach(), iy)]
+    return _CosineMeans.apply(tuple(float(w) for *_, w in terms), *flat)
 
 
 def cosine_mean(X, ix, Y, iy):

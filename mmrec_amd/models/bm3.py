@@ -132,20 +132,20 @@ class BM3(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecomm
         v_tgt = rest.pop(0) if v_on is not None else None
         # six BYOL terms 1 - mean cos(online, detached target): each ONE fused gather-dot-norm kernel (+ one scatter
         # kernel backward) instead of ~20 elementwise / reduction launches (bm3.py:129-144)
-        cos = hip_ops.cosine_mean
+        # (round 6: ALL of them in one launch pair -- hip_ops.cosine_means, ABI 14 -- as const - sum_t w_t mean cos_t)
         u_pred, i_pred = self._predict(u_ori), self._predict(i_ori)
-        loss_t = loss_v = loss_tv = loss_vt = 0.0
+        cl = float(self.cl_weight)
+        terms, const = [(u_pred, users, i_tgt, items, -1.0), (i_pred, items, u_tgt, users, -1.0)], 2.0      # loss_ui, loss_iu
         if t_on is not None:
             t_pred, t_idx = self._predict(t_on), (None if lazy else items)
             t_tgt = t_on.detach() * t_tgt[items_ds, :] if lazy else t_tgt
-            loss_t = 1 - cos(t_pred, t_idx, i_tgt, items)
-            loss_tv = 1 - cos(t_pred, t_idx, t_tgt, t_idx)
+            terms += [(t_pred, t_idx, i_tgt, items, -cl), (t_pred, t_idx, t_tgt, t_idx, -cl)]                # loss_t, loss_tv
+            const += 2.0 * cl
         if v_on is not None:
             v_pred, v_idx = self._predict(v_on), (None if lazy else items)
             v_tgt = v_on.detach() * v_tgt[items_ds, :] if lazy else v_tgt
-            loss_v = 1 - cos(v_pred, v_idx, i_tgt, items)
-            loss_vt = 1 - cos(v_pred, v_idx, v_tgt, v_idx)
-        loss_ui = 1 - cos(u_pred, users, i_tgt, items)
-        loss_iu = 1 - cos(i_pred, items, u_tgt, users)
-        reg = (torch.norm(u_ori, p=2) + torch.norm(i_ori, p=2)) / i_ori.shape[0]   # EmbLoss(u, i)
-        return (loss_ui + loss_iu) + self.reg_weight * reg + self.cl_weight * (loss_t + loss_v + loss_tv + loss_vt)
+            terms += [(v_pred, v_idx, i_tgt, items, -cl), (v_pred, v_idx, v_tgt, v_idx, -cl)]                # loss_v, loss_vt
+            const += 2.0 * cl
+        # EmbLoss(u, i) = (||u|| + ||i||) / n_items over the WHOLE tables (bm3.py:146), times reg_weight: one launch pair
+        reg = hip_ops.rows_reg(((u_ori, None), (i_ori, None)), hip_ops.ROWS_REG_NORM, float(self.reg_weight) / i_ori.shape[0])
+        return const + hip_ops.cosine_means(terms) + reg

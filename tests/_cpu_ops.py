@@ -223,6 +223,14 @@ def cosine_mean(X, ix, Y, iy):
     return F.cosine_similarity(x, y, dim=-1).mean()
 
 
+def cosine_means(terms):
+    """hip_ops.cosine_means: sum_t w_t mean cos(X_t[ix_t], Y_t[iy_t])"""
+    total = 0.0
+    for X, ix, Y, iy, w in terms:
+        total = total + w * cosine_mean(X, ix, Y, iy)
+    return total
+
+
 def gather_sqnorm(E, ids):
     _mat(E, "E"), _ids(ids, "ids")
     return (E[ids] ** 2).sum()
@@ -238,7 +246,7 @@ def rows_reg(terms, mode, scale=1.0):
     """hip_ops.rows_reg (ABI 14): scale * sum_t ||E_t[ids_t]||_F^2 (mode 0) or scale * sum_t ||E_t[ids_t]||_F (mode 1)"""
     total = 0.0
     for E, ids in terms:
-        s = gather_sqnorm(E, ids)
+        s = (E ** 2).sum() if ids is None else gather_sqnorm(E, ids)
         total = total + (s if mode == 0 else torch.sqrt(s))
     return scale * total
 
@@ -339,7 +347,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "rows_reg", "cat_leaky", "cosine_mean", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "rows_reg", "cat_leaky", "cosine_mean", "cosine_means", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

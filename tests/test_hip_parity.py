@@ -754,6 +754,41 @@ def test_cosine_mean_fwd_bwd_vs_torch(ops, dev):
             close(Xd.grad, 3.0 * Xc.grad, rtol=1e-4, atol=1e-7)
 
 
+def test_cosine_means_fused_terms(ops, dev):
+    """ABI 14 mmrec_cosine_multi_fwd/bwd_f32 (hip_ops.cosine_means): BM3's six BYOL terms (bm3.py:129-144) as one launch pair --
+    sum_t w_t mean_b cos(X_t[ix_t[b]], Y_t[iy_t[b]]) against torch: value and gradients; indexed and un-indexed operands, an X
+    shared by two terms (one dense gradient), duplicate ids, a zero row (the 1e-8 clamp), batches that are no multiple of 16,
+    128-wide rows, an upstream gradient != 1; rows_reg over WHOLE tables (ids None: bm3.py:146's EmbLoss) rides along."""
+    g = torch.Generator().manual_seed(21)
+    for d in (64, 128):
+        nU, nI, B = 60, 45, 101
+        Up, Ip, Tp = (torch.randn(nU, d, generator=g).requires_grad_(), torch.randn(nI, d, generator=g).requires_grad_(),
+                      torch.randn(B, d, generator=g).requires_grad_())
+        It, Ut, Tt = torch.randn(nI, d, generator=g), torch.randn(nU, d, generator=g), torch.randn(B, d, generator=g)
+        with torch.no_grad():
+            Ip[3].zero_()
+        users, items = torch.randint(0, nU, (B,), generator=g), torch.randint(0, nI, (B,), generator=g)
+        items[:10] = 3
+        spec = [(0, users, It, items, -1.0), (1, items, Ut, users, -1.0), (2, None, It, items, -0.4), (2, None, Tt, None, -0.4)]
+        cpu_x = (Up, Ip, Tp)
+        cosf = torch.nn.functional.cosine_similarity
+        ref = sum(w * cosf(cpu_x[k] if ix is None else cpu_x[k][ix], Y if iy is None else Y[iy], dim=-1).mean() for k, ix, Y, iy, w in spec)
+        reg_ref = 0.02 * (torch.norm(Up) + torch.norm(Ip))
+        (1.3 * (ref + reg_ref)).backward()
+        dx = [t.detach().to(dev).requires_grad_() for t in cpu_x]
+        mv = lambda t: None if t is None else t.to(dev)
+        terms = [(dx[k], mv(ix), Y.to(dev), mv(iy), w) for k, ix, Y, iy, w in spec]
+        out = ops.cosine_means(terms)
+        reg = ops.rows_reg(((dx[0], None), (dx[1], None)), ops.ROWS_REG_NORM, 0.02)
+        (1.3 * (out + reg)).backward()
+        close(out, ref, rtol=1e-5, atol=1e-6)
+        close(reg, reg_ref, rtol=2e-6)
+        for a, b in zip(dx, cpu_x):
+            close(a.grad, b.grad, rtol=1e-4, atol=2e-7)
+        per = sum(w * ops.cosine_mean(x.detach(), ix, Y, iy) for x, ix, Y, iy, w in terms)
+        close(out, per, rtol=1e-5, atol=1e-6)
+
+
 def test_gather_sqnorm(ops, dev):
     g = torch.Generator().manual_seed(4)
     E = torch.randn(40, 64, generator=g).requires_grad_()
