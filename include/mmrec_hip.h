@@ -218,6 +218,13 @@ int mmrec_cosine_multi_bwd_f32(const float* const* X, const int64_t* const* ix, 
                                const float* w, const int32_t* batch, int32_t n_terms, int32_t d, const float* coef,
                                const float* grad_scalar, float* const* dX, mmrec_stream_t stream);
 
+/* ABI 14 -- F.normalize(x, p=2, dim=1) in one launch each way (lattice.py:165, mmgcn.py:167): Y = X / max(||X_row||, eps),
+ * inv[row] = +- 1 / max(||X_row||, eps) (out, for the backward; negative: the clamp was active); bwd: dX = |inv| (G - Y (Y . G))
+ * (clamp active: |inv| G).  Rows of d % 4 == 0 floats. */
+int mmrec_row_normalize_fwd_f32(const float* X, int64_t n, int32_t d, float eps, float* Y, float* inv, mmrec_stream_t stream);
+int mmrec_row_normalize_bwd_f32(const float* Y, const float* G, const float* inv, int64_t n, int32_t d, float* dX,
+                                mmrec_stream_t stream);
+
 /* ABI 14 -- the elementwise tail of an MMGCN layer (mmgcn.py:170-173, :176-179, :182-185) in one launch each way:
  *   fwd: out [n, wa + wb] = [ leaky_relu(A [n, wa]) | leaky_relu(B [n, wb]) + R [n, wb] ]   (R may be NULL; wa, wb % 4 == 0)
  *   bwd: dA = dOut[:, :wa] * (A > 0 ? 1 : slope), dB likewise from dOut[:, wa:], dR = dOut[:, wa:] (each may be NULL)

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mmrec_cosine_multi_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mmrec_cosine_multi_fwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     "mmrec_cosine_multi_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
+    "mmrec_row_normalize_fwd_f32": (c_int32, [_P, c_int64, c_int32, c_float, _P, _P, _P]),
+    "mmrec_row_normalize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "mmrec_cat_leaky_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, _P, _P]),
     "mmrec_cat_leaky_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, _P]),
     "mmrec_rows_reg_workspace_bytes": (c_size_t, [c_int32, c_int32]),

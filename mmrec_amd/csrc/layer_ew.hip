@@ -52,7 +52,68 @@ __global__ __launch_bounds__(256) void cat_leaky_bwd_kernel(const float4* __rest
     }
 }
 
+// F.normalize(x, p=2, dim=1) (lattice.py:165, mmgcn.py:167): y = x / max(||x||, 1e-12) -- four launches forward (norm, clamp,
+// expand, div) and half a dozen backward in torch; here one each way.  A 16-lane group per row (d = 4 w4 floats, any w4).
+// inv[row] = 1 / max(||x||, eps) is kept for the backward: dx = inv (g - y (y . g)) where the clamp is inactive, inv g where it is
+// (the norm is then a constant), as autograd derives it from the four ops.
+__global__ __launch_bounds__(256) void row_normalize_fwd_kernel(const float4* __restrict__ X, size_t n, int w4, float eps,
+                                                                float4* __restrict__ Y, float* __restrict__ inv) {
+    const int lane16 = threadIdx.x & 15;
+    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= n) return;
+    float t = 0.f;
+    for (int k = lane16; k < w4; k += 16) {
+        const float4 x = X[row * w4 + k];
+        t += f4_dot(x, x);
+    }
+    const float nrm = sqrtf(row16_sum(t));
+    const float r = 1.0f / fmaxf(nrm, eps);
+    for (int k = lane16; k < w4; k += 16) Y[row * w4 + k] = f4_scale(r, X[row * w4 + k]);
+    if (lane16 == 0) inv[row] = nrm > eps ? r : -r;      // sign bit: the clamp was active
+}
+
+__global__ __launch_bounds__(256) void row_normalize_bwd_kernel(const float4* __restrict__ Y, const float4* __restrict__ G,
+                                                                const float* __restrict__ inv, size_t n, int w4,
+                                                                float4* __restrict__ dX) {
+    const int lane16 = threadIdx.x & 15;
+    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= n) return;
+    const float r = inv[row];
+    float t = 0.f;
+    if (r > 0.f)
+        for (int k = lane16; k < w4; k += 16) t += f4_dot(Y[row * w4 + k], G[row * w4 + k]);
+    const float yg = row16_sum(t);
+    const float a = fabsf(r);
+    for (int k = lane16; k < w4; k += 16) {
+        const float4 y = Y[row * w4 + k], g = G[row * w4 + k];
+        dX[row * w4 + k] = make_float4(a * (g.x - y.x * yg), a * (g.y - y.y * yg), a * (g.z - y.z * yg), a * (g.w - y.w * yg));
+    }
+}
+
 }  // namespace
+
+extern "C" int mmrec_row_normalize_fwd_f32(const float* X, int64_t n, int32_t d, float eps, float* Y, float* inv,
+                                           mmrec_stream_t stream) {
+    if (d <= 0 || (d & 3)) return MMREC_ERR_UNSUPPORTED;
+    if (n < 0) return MMREC_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!X || !Y || !inv) return MMREC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(row_normalize_fwd_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, mmrec_stream(stream),
+                       reinterpret_cast<const float4*>(X), (size_t)n, d / 4, eps, reinterpret_cast<float4*>(Y), inv);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_row_normalize_bwd_f32(const float* Y, const float* G, const float* inv, int64_t n, int32_t d, float* dX,
+                                           mmrec_stream_t stream) {
+    if (d <= 0 || (d & 3)) return MMREC_ERR_UNSUPPORTED;
+    if (n < 0) return MMREC_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!Y || !G || !inv || !dX) return MMREC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, mmrec_stream(stream),
+                       reinterpret_cast<const float4*>(Y), reinterpret_cast<const float4*>(G), inv, (size_t)n, d / 4,
+                       reinterpret_cast<float4*>(dX));
+    MMREC_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int mmrec_cat_leaky_fwd_f32(const float* A, const float* B, const float* R, int64_t n, int32_t wa, int32_t wb, float slope,
                                        float* out, mmrec_stream_t stream) {

@@ -1037,6 +1037,36 @@ def rows_reg(terms, mode, scale=1.0):
     return _RowsReg.apply(mode, scale, *flat)
 
 
+class _RowNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, eps):
+        lib = _lib.load()
+        X = _chk(X.contiguous(), torch.float32, "X", 2)
+        if X.shape[1] % 4:
+            raise _lib.MMRecHipError("row_normalize: rows of a multiple of 4 floats")
+        Y = torch.empty_like(X)
+        inv = torch.empty(max(X.shape[0], 1), dtype=torch.float32, device=X.device)
+        _lib.check(lib.mmrec_row_normalize_fwd_f32(_p(X), X.shape[0], X.shape[1], float(eps), _p(Y), _p(inv), _stream()),
+                   "row_normalize_fwd")
+        ctx.save_for_backward(Y, inv)
+        return Y
+
+    @staticmethod
+    def backward(ctx, G):
+        lib = _lib.load()
+        Y, inv = ctx.saved_tensors
+        G = G.contiguous()
+        dX = torch.empty_like(Y)
+        _lib.check(lib.mmrec_row_normalize_bwd_f32(_p(Y), _p(G), _p(inv), Y.shape[0], Y.shape[1], _p(dX), _stream()),
+                   "row_normalize_bwd")
+        return dX, None
+
+
+def row_normalize(X, eps=1e-12):
+    """F.normalize(X, p=2, dim=1) in one launch each way (lattice.py:165, mmgcn.py:167)."""
+    return _RowNormalize.apply(X, eps)
+
+
 class _CatLeaky(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, B, R, slope):

@@ -184,7 +184,7 @@ class LATTICE(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
         h = self.item_id_embedding.weight
         for _ in range(self.n_layers):
             h = hip_ops.spmm_vals(dyn, h, vals)
-        h = F.normalize(h, p=2, dim=1)
+        h = hip_ops.row_normalize(h)              # F.normalize(h, p=2, dim=1) (lattice.py:165), one launch each way
         if self.cf_model == 'mf':
             return self.user_embedding.weight, self.item_id_embedding.weight + h
         ego = torch.cat((self.user_embedding.weight, self.item_id_embedding.weight), dim=0)

@@ -94,7 +94,7 @@ class GCN(nn.Module):
 
     def forward(self, features, id_embedding, graph):
         temp = _lin64(self.MLP, features) if self.dim_latent else features
-        x = F.normalize(torch.cat((self.preference, temp), dim=0))
+        x = hip_ops.row_normalize(torch.cat((self.preference, temp), dim=0))      # F.normalize (mmgcn.py:167-168)
         for conv, lin, gl in ((self.conv_embed_1, self.linear_layer1, self.g_layer1),
                               (self.conv_embed_2, self.linear_layer2, self.g_layer2),
                               (self.conv_embed_3, self.linear_layer3, self.g_layer3)):

@@ -236,6 +236,10 @@ def gather_sqnorm(E, ids):
     return (E[ids] ** 2).sum()
 
 
+def row_normalize(X, eps=1e-12):
+    return F.normalize(X, p=2, dim=1, eps=eps)
+
+
 def cat_leaky(A, B, R=None, slope=0.01):
     """hip_ops.cat_leaky: cat((leaky_relu(A), leaky_relu(B) + R), dim=1)"""
     x_hat = F.leaky_relu(B, slope)
@@ -347,7 +351,7 @@ def spmm_vals(dyn, X, vals):
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "infonce",
-            "gather_sqnorm", "rows_reg", "cat_leaky", "cosine_mean", "cosine_means", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
+            "gather_sqnorm", "rows_reg", "cat_leaky", "row_normalize", "cosine_mean", "cosine_means", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 
 

@@ -862,6 +862,28 @@ def test_cat_leaky_fused_layer_tail(ops, dev, n, wa, wb, with_r):
         out2.sum().backward()
 
 
+@pytest.mark.parametrize("n,d", [(333, 64), (50, 256), (1000, 384), (7, 4)])
+def test_row_normalize_fused(ops, dev, n, d):
+    """ABI 14 mmrec_row_normalize_fwd/bwd_f32 (hip_ops.row_normalize) == F.normalize(x, p=2, dim=1) (lattice.py:165, mmgcn.py:167):
+    values and gradients to fp32 rounding, an all-zero row and a row below the 1e-12 clamp (norm treated as a constant) included."""
+    g = torch.Generator().manual_seed(n + d)
+    X = torch.randn(n, d, generator=g)
+    X[1] = 0.0
+    X[2] *= 1e-20
+    X[3] *= 1e4
+    G = torch.randn(n, d, generator=g)
+    x = X.clone().requires_grad_()
+    ref = torch.nn.functional.normalize(x, p=2, dim=1)
+    ref.backward(G)
+    xd = X.to(dev).requires_grad_()
+    out = ops.row_normalize(xd)
+    out.backward(G.to(dev))
+    close(out, ref.detach(), rtol=2e-6, atol=1e-7)
+    row_scale = x.grad.abs().max(dim=1, keepdim=True)[0]          # (the clamped rows' gradients are g / 1e-12: per-row scales)
+    assert bool(((xd.grad.cpu() - x.grad).abs() <= 4e-6 * row_scale + 1e-12).all())
+    assert torch.isfinite(xd.grad).all() and float(out[1].abs().max()) == 0.0
+
+
 def test_infonce_fwd_bwd_vs_oracle(ops, dev):
     """In-batch InfoNCE incl. duplicate ids (scatter-add), batch not a multiple of the 64-row tile,
     a zero row (normalisation eps) and asymmetric views."""
