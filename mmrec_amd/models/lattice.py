@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from mmrec_amd import hip_ops
 from mmrec_amd.graph import relabel_graph
-from mmrec_amd.models._base import FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
+from mmrec_amd.models._base import AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender, RelabelledIdsMixin
 
 
 def _sym_norm_values(rows, cols, vals, n):
@@ -29,11 +29,12 @@ def _sym_norm_values(rows, cols, vals, n):
     return d[rows] * vals * d[cols]
 
 
-class LATTICE(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
+class LATTICE(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecommender):
     # the first batch of an epoch builds the learned item graph (lattice.py:137-159), later ones reuse it: that batch runs
     # eagerly, the step is captured on the second one and replayed for the rest of the epoch (common/graph_step.py)
     graph_capturable = True
     graph_eager_batches = 1
+    adjacent_tables = ('user_embedding.weight', 'item_id_embedding.weight')     # the cat of lattice.py:184 already exists
     relabelled_tables = {'user_embedding.weight': 'u', 'item_id_embedding.weight': 'i', 'image_embedding.weight': 'i',
                          'text_embedding.weight': 'i'}     # config key `reorder` (models/_base.py)
 
@@ -187,10 +188,11 @@ class LATTICE(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
         h = hip_ops.row_normalize(h)              # F.normalize(h, p=2, dim=1) (lattice.py:165), one launch each way
         if self.cf_model == 'mf':
             return self.user_embedding.weight, self.item_id_embedding.weight + h
+        if self.cf_model == 'lightgcn':       # (the two tables as row blocks: no cat forward, no split / zero-filled halves backward)
+            u_g, i_g = hip_ops.lightgcn_mean_parts(adj, (self.user_embedding.weight, self.item_id_embedding.weight), self.n_ui_layers)
+            return u_g, i_g + h
         ego = torch.cat((self.user_embedding.weight, self.item_id_embedding.weight), dim=0)
-        if self.cf_model == 'lightgcn':
-            mean = hip_ops.lightgcn_mean(adj, ego, self.n_ui_layers)
-        elif self.cf_model == 'ngcf':
+        if self.cf_model == 'ngcf':
             layers = [ego]
             for i in range(self.n_ui_layers):
                 side = hip_ops.spmm(adj, ego)
