@@ -403,6 +403,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           int* __restrict__ redo = nullptr) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_elems) return;
+    part += (size_t)blockIdx.y * nslab * slab_elems;      // (grid.y > 1: the 64-output groups of a wide dW, each with its own slabs)
+    out += (size_t)blockIdx.y * slab_elems;
     // four independent chains keep the slab loads in flight (a single chain of up to 64 dependent
     // adds was latency bound: 17 us for a few MB); the combination order is still fixed
     float4 t0 = f4_zero(), t1 = f4_zero(), t2 = f4_zero(), t3 = f4_zero();
@@ -439,7 +441,11 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ X,
                                                            float* __restrict__ part,
                                                            float* __restrict__ dbpart, int n, int F,
-                                                           int n_chunk, int ldg) {
+                                                           int n_chunk, int ldg, size_t zs_part, size_t zs_db) {
+    // blockIdx.z = the 64-output group (out > 64: MMGCN's 256 / 384-wide layers): its columns of dY, its slabs, its db partials
+    dY += 64 * blockIdx.z;
+    part += blockIdx.z * zs_part;
+    if (dbpart) dbpart += blockIdx.z * zs_db;
     __shared__ __attribute__((aligned(16))) float Gs[BW_BK][64];
     __shared__ __attribute__((aligned(16))) float Xs[BW_BK][BW_BF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -512,7 +518,11 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_w_dma_kernel(const float* _
                                                                   const float* __restrict__ X,
                                                                   float* __restrict__ part,
                                                                   float* __restrict__ dbpart, int n, int F,
-                                                                  int n_chunk, int ldg) {
+                                                                  int n_chunk, int ldg, size_t zs_part, size_t zs_db) {
+    // blockIdx.z = the 64-output group (out > 64: MMGCN's 256 / 384-wide layers): its columns of dY, its slabs, its db partials
+    dY += 64 * blockIdx.z;
+    part += blockIdx.z * zs_part;
+    if (dbpart) dbpart += blockIdx.z * zs_db;
     __shared__ __attribute__((aligned(1024))) float G0[BW_BK * 64], G1[BW_BK * 64], G2[BW_BK * 64];
     __shared__ __attribute__((aligned(1024))) float X0[BW_BK * BW_BF], X1[BW_BK * BW_BF], X2[BW_BK * BW_BF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -583,6 +593,8 @@ __global__ __launch_bounds__(1024) void db_reduce_kernel(const float* __restrict
                                                          float* __restrict__ db) {
     __shared__ float red[16][64];
     const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    dbpart += (size_t)blockIdx.x * nsplit * 64;           // (one workgroup per 64-output group)
+    db += 64 * blockIdx.x;
     float t = 0.f;
     for (int s = sl; s < nsplit; s += 16) t += dbpart[s * 64 + c];
     red[sl][c] = t;
@@ -1255,7 +1267,7 @@ extern "C" size_t mmrec_linear_workspace_bytes(int32_t n, int32_t F, int32_t out
     // the redo flags of its domain check (one per 128-row block + one per W row)
     const size_t fwd = ((s1 > 1 ? (size_t)s1 * n * 64 * sizeof(float) : 0) + 255) / 256 * 256 + (size_t)64 * F * sizeof(float) +
                        (s1 > 1 ? (size_t)s1 * n * sizeof(float) : 0) + ((size_t)ceil_div(n, LIN_BM) + 64) * sizeof(int);
-    const size_t bww = ((s2 > 1 ? (size_t)s2 * 64 * F : 0) + (size_t)s2 * 64) * sizeof(float);
+    const size_t bww = ((s2 > 1 ? (size_t)s2 * 64 * F : 0) + (size_t)s2 * 64) * sizeof(float) * (size_t)(out / 64);   // every 64-output group its own slabs
     return fwd > bww ? fwd : bww;
 }
 
@@ -1483,24 +1495,25 @@ extern "C" int mmrec_linear_bwd_w_f32(const float* dY, const float* X, float* dW
     pick_split(ceil_div(F, BW_BF), n, BW_BK, &nsplit, &chunk);
     if (!workspace) return MMREC_ERR_BAD_ARG;
     float* part = static_cast<float*>(workspace);
-    // workspace layout: [nsplit > 1 ? nsplit*64*F : 0] dW partial slabs, then [nsplit*64] db partials
-    float* dbpart = db ? part + (nsplit > 1 ? (size_t)nsplit * 64 * F : 0) : nullptr;
-    for (int z = 0; z < out / 64; ++z) {
-        const float* g = dY + 64 * z;
-        float* dWz = dW + (size_t)64 * z * F;
-        const bool dma = (size_t)chunk * F * 4 < ((size_t)1 << 31) && (size_t)chunk * out * 4 < ((size_t)1 << 31) &&
-                         !MMREC_GEMM_LEGACY_FWD;
-        auto kern = dma ? linear_bwd_w_dma_kernel : linear_bwd_w_kernel;
-        if (nsplit == 1) {
-            hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), 1), dim3(256), 0, s, g, X, dWz, dbpart, n, F, chunk, out);
-        } else {
-            hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), nsplit), dim3(256), 0, s, g, X, part, dbpart, n, F, chunk, out);
-            const size_t elems = (size_t)64 * F;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0,
-                               s, part, nsplit, elems, (const float*)nullptr, dWz);
-        }
-        if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(1), dim3(1024), 0, s, dbpart, nsplit, db + 64 * z);
+    // workspace layout: per 64-output group z [nsplit > 1 ? nsplit*64*F : 0] dW partial slabs, then per z [nsplit*64] db partials.
+    // ALL groups in one launch (grid.z; round 6: MMGCN's 256 / 384-wide layers sent 4 / 6 launches of 128-192 workgroups each)
+    const int nz = out / 64;
+    const size_t slab_z = nsplit > 1 ? (size_t)nsplit * 64 * F : 0;
+    float* dbpart = db ? part + slab_z * nz : nullptr;
+    const bool dma = (size_t)chunk * F * 4 < ((size_t)1 << 31) && (size_t)chunk * out * 4 < ((size_t)1 << 31) &&
+                     !MMREC_GEMM_LEGACY_FWD;
+    auto kern = dma ? linear_bwd_w_dma_kernel : linear_bwd_w_kernel;
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), 1, nz), dim3(256), 0, s, dY, X, dW, dbpart, n, F, chunk, out,
+                           (size_t)64 * F, (size_t)nsplit * 64);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(ceil_div(F, BW_BF), nsplit, nz), dim3(256), 0, s, dY, X, part, dbpart, n, F, chunk, out, slab_z,
+                           (size_t)nsplit * 64);
+        const size_t elems = (size_t)64 * F;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256), nz), dim3(256), 0,
+                           s, part, nsplit, elems, (const float*)nullptr, dW);
     }
+    if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3(nz), dim3(1024), 0, s, dbpart, nsplit, db);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 
