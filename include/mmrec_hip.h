@@ -203,6 +203,22 @@ int mmrec_rows_reg_fwd_f32(const float* const* E, const int64_t* const* ids, con
 int mmrec_rows_reg_bwd_f32(const float* const* E, const int64_t* const* ids, const int32_t* batch, int32_t n_terms, int32_t d,
                            const float* coef, const float* g, float* const* dE, mmrec_stream_t stream);
 
+/* ABI 14 -- several BPR terms over the SAME user rows in one forward call (two launches) and one backward launch:
+ *   losses[t] = scale * sum_b loss(<U[users[b]], I[t][pos[t][b]]> - <U[users[b]], I[t][neg[t][b]]>)  (losses may be NULL),
+ *   total[0] = sum_t w[t] * losses[t];  coef [n_terms][batch] as mmrec_bpr_fwd_f32's per term;  n_terms <= MMREC_BPR_MAX_TERMS.
+ *   bwd: dU[users[b]] += c (p - n), dI[t][pos] += c u, dI[t][neg] -= c u with c = g[0] scale w[t] coef[t][b] (fp32 atomics; dU or
+ *   any dI[t] may be NULL).  I, pos, neg, w, dI are HOST arrays of n_terms entries.
+ * replaces: bpr_loss(id) + reg_weight * (bpr_loss(text) + bpr_loss(image)) of freedom.py:197-211 (per-term form:
+ * mmrec_bpr_fwd_f32 / mmrec_bpr_bwd_f32 and the scalar launches that weight and add the three losses). */
+#define MMREC_BPR_MAX_TERMS 4
+size_t mmrec_bpr_multi_workspace_bytes(int32_t n_terms, int32_t batch);
+int mmrec_bpr_multi_fwd_f32(const float* U, const int64_t* users, const float* const* I, const int64_t* const* pos,
+                            const int64_t* const* neg, const float* w, int32_t n_terms, int32_t batch, int32_t d, int32_t variant,
+                            float scale, float* total, float* losses, float* coef, void* workspace, mmrec_stream_t stream);
+int mmrec_bpr_multi_bwd_f32(const float* U, const int64_t* users, const float* const* I, const int64_t* const* pos,
+                            const int64_t* const* neg, const float* w, int32_t n_terms, int32_t batch, int32_t d, const float* coef,
+                            const float* grad_scalar, float scale, float* dU, float* const* dI, mmrec_stream_t stream);
+
 /* ABI 14 -- several mean-cosine terms in one forward call (two launches) and one backward launch:
  *   out[0] = sum_t w[t] * mean_b cos(X[t][ix[t][b]], Y[t][iy[t][b]])   (ix[t] / iy[t] NULL: row b; Y constant; F.cosine_similarity's
  *   1e-8 clamp; n_terms <= MMREC_COSINE_MAX_TERMS, rows of d = 64 k floats), coef [n_terms][max_batch][2] as mmrec_cosine_fwd_f32's;

@@ -85,6 +85,9 @@ SIGNATURES = {
     "mmrec_cosine_workspace_bytes": (c_size_t, [c_int32]),
     "mmrec_cosine_fwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, _P, _P, _P]),
     "mmrec_cosine_bwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, _P, c_float, _P, _P]),
+    "mmrec_bpr_multi_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "mmrec_bpr_multi_fwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P]),
+    "mmrec_bpr_multi_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_float, _P, _P, _P]),
     "mmrec_cosine_multi_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mmrec_cosine_multi_fwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     "mmrec_cosine_multi_bwd_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),

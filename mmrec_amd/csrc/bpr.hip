@@ -165,6 +165,112 @@ __global__ __launch_bounds__(256) void gather_scale_add_kernel(const float* __re
     }
 }
 
+// ---- several BPR terms over the SAME user rows in one launch pair (ABI 14): FREEDOM's id term and its two modality terms,
+// total = sum_t w_t scale sum_b loss(<u, p_t> - <u, n_t>) (freedom.py:197-211: bpr + reg_weight (mf_t + mf_v)).  Per term the step
+// ran bpr_fwd_kernel + reduce_sum_kernel, then three scalar launches to weight and add the losses, and on the way back two
+// scalar launches and one bpr_bwd_kernel per term: 9 + 5 launches for what is 2 + 1 here (grid.y = term).  Per-sample arithmetic
+// is bpr_fwd_kernel's / bpr_bwd_kernel's; losses[t] = scale sum_b loss_t as the per-term call leaves it.
+struct BprTerms {
+    const float* I[MMREC_BPR_MAX_TERMS];
+    const int64_t* pos[MMREC_BPR_MAX_TERMS];
+    const int64_t* neg[MMREC_BPR_MAX_TERMS];
+    float* dI[MMREC_BPR_MAX_TERMS];
+    float w[MMREC_BPR_MAX_TERMS];
+    int n_terms;
+};
+
+__global__ __launch_bounds__(256) void bpr_multi_fwd_kernel(const float* __restrict__ U, const int64_t* __restrict__ users,
+                                                            const BprTerms a, int batch, int d4, int variant,
+                                                            float* __restrict__ part, float* __restrict__ coef) {
+    __shared__ float s_row[16];
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int b = blockIdx.x * 16 + g;
+    float l = 0.f;
+    if (b < batch) {
+        const size_t iu = (size_t)users[b] * d4, ip = (size_t)a.pos[t][b] * d4, in = (size_t)a.neg[t][b] * d4;
+        float pp = 0.f, nn = 0.f;
+        for (int c = lane16; c < d4; c += 16) {
+            const float4 u = reinterpret_cast<const float4*>(U)[iu + c];
+            pp += f4_dot(u, reinterpret_cast<const float4*>(a.I[t])[ip + c]);
+            nn += f4_dot(u, reinterpret_cast<const float4*>(a.I[t])[in + c]);
+        }
+        const float x = row16_sum(pp) - row16_sum(nn);
+        float c;
+        if (variant == MMREC_BPR_LOGSIG) {
+            l = neg_logsigmoid(x);
+            c = -1.0f / (1.0f + expf(x));
+        } else {
+            const float sg = 1.0f / (1.0f + expf(-x));
+            l = -logf(1e-10f + sg);
+            c = -(sg * (1.0f - sg)) / (1e-10f + sg);
+        }
+        if (lane16 == 0) coef[(size_t)t * batch + b] = c;
+    }
+    if (lane16 == 0) s_row[g] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) {                              // the block's 16 losses in sample order
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += s_row[i];
+        part[(size_t)t * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_multi_finish_kernel(const BprTerms a, const float* __restrict__ part, int n_blocks,
+                                                               float scale, float* __restrict__ total, float* __restrict__ losses) {
+    __shared__ float red[MMREC_BPR_MAX_TERMS][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float x[MMREC_BPR_MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < MMREC_BPR_MAX_TERMS; ++t) {
+        x[t] = 0.f;
+        if (t < a.n_terms)
+            for (int i = threadIdx.x; i < n_blocks; i += 256) x[t] += part[(size_t)t * n_blocks + i];
+    }
+#pragma unroll
+    for (int t = 0; t < MMREC_BPR_MAX_TERMS; ++t) {
+        if (t < a.n_terms) {
+            const float w = wave_sum(x[t]);
+            if (lane == 0) red[t][wave] = w;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int t = 0; t < a.n_terms; ++t) {
+            const float lt = scale * ((red[t][0] + red[t][1]) + (red[t][2] + red[t][3]));
+            if (losses) losses[t] = lt;
+            tot += a.w[t] * lt;
+        }
+        total[0] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_multi_bwd_kernel(const float* __restrict__ U, const int64_t* __restrict__ users,
+                                                            const BprTerms a, int batch, int d4, const float* __restrict__ coef,
+                                                            const float* __restrict__ grad_scalar, float scale,
+                                                            float* __restrict__ dU) {
+    const int t = blockIdx.y, lane16 = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= batch) return;
+    const size_t ru = (size_t)users[b] * d4, rp = (size_t)a.pos[t][b] * d4, rn = (size_t)a.neg[t][b] * d4;
+    const float c = grad_scalar[0] * scale * a.w[t] * coef[(size_t)t * batch + b];
+    float* dI = a.dI[t];
+    for (int k = lane16; k < d4; k += 16) {
+        const size_t iu = ru + k, ip = rp + k, in = rn + k;
+        if (dU) {
+            const float4 p = reinterpret_cast<const float4*>(a.I[t])[ip];
+            const float4 n = reinterpret_cast<const float4*>(a.I[t])[in];
+            atomic_add_f4(dU + iu * 4, make_float4(c * (p.x - n.x), c * (p.y - n.y), c * (p.z - n.z), c * (p.w - n.w)));
+        }
+        if (dI) {
+            const float4 u = reinterpret_cast<const float4*>(U)[iu];
+            atomic_add_f4(dI + ip * 4, f4_scale(c, u));
+            atomic_add_f4(dI + in * 4, f4_scale(-c, u));
+        }
+    }
+}
+
 // ---- several mean-cosine terms in one launch pair (ABI 14): BM3's six BYOL terms (bm3.py:129-144) ---------------------------------
 // out = sum_t w_t mean_b cos(X_t[ix_t[b]], Y_t[iy_t[b]]) with cosine_fwd_kernel's arithmetic per row; the per-term calls were
 // 6 x (rows, sum) launches forward and 6 backward plus ~25 elementwise launches for the `1 - .` / weights / sums around them,
@@ -531,6 +637,58 @@ extern "C" int mmrec_gather_scale_add_bwd_f32(const float* E, const int64_t* ids
     if (!E || !ids || !coef_scalar || !dE) return MMREC_ERR_BAD_ARG;
     hipLaunchKernelGGL(gather_scale_add_kernel, dim3((batch + 15) / 16), dim3(256), 0,
                        mmrec_stream(stream), E, ids, batch, d / 4, coef_scalar, dE);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+namespace {
+int bpr_terms(BprTerms& a, const float* const* I, const int64_t* const* pos, const int64_t* const* neg, const float* w,
+              float* const* dI, int32_t n_terms, int32_t batch) {
+    if (n_terms < 1 || n_terms > MMREC_BPR_MAX_TERMS || !I || !pos || !neg || !w) return MMREC_ERR_BAD_ARG;
+    a.n_terms = n_terms;
+    for (int t = 0; t < n_terms; ++t) {
+        if (batch > 0 && (!I[t] || !pos[t] || !neg[t])) return MMREC_ERR_BAD_ARG;
+        a.I[t] = I[t], a.pos[t] = pos[t], a.neg[t] = neg[t], a.w[t] = w[t], a.dI[t] = dI ? dI[t] : nullptr;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t mmrec_bpr_multi_workspace_bytes(int32_t n_terms, int32_t batch) {
+    return (size_t)(n_terms > 0 ? n_terms : 0) * (size_t)(((batch > 0 ? batch : 0) + 15) / 16) * sizeof(float) + 64;
+}
+
+extern "C" int mmrec_bpr_multi_fwd_f32(const float* U, const int64_t* users, const float* const* I, const int64_t* const* pos,
+                                       const int64_t* const* neg, const float* w, int32_t n_terms, int32_t batch, int32_t d,
+                                       int32_t variant, float scale, float* total, float* losses, float* coef, void* workspace,
+                                       mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    if (variant != MMREC_BPR_LOGSIG && variant != MMREC_BPR_GAMMA) return MMREC_ERR_BAD_ARG;
+    if (batch < 0 || !total) return MMREC_ERR_BAD_ARG;
+    BprTerms a;
+    if (int err = bpr_terms(a, I, pos, neg, w, nullptr, n_terms, batch)) return err;
+    if (batch > 0 && (!U || !users || !coef || !workspace)) return MMREC_ERR_BAD_ARG;
+    hipStream_t s = mmrec_stream(stream);
+    const int n_blocks = (batch + 15) / 16;
+    if (batch > 0)
+        hipLaunchKernelGGL(bpr_multi_fwd_kernel, dim3(n_blocks, n_terms), dim3(256), 0, s, U, users, a, batch, d / 4, variant,
+                           static_cast<float*>(workspace), coef);
+    hipLaunchKernelGGL(bpr_multi_finish_kernel, dim3(1), dim3(256), 0, s, a, static_cast<const float*>(workspace), n_blocks, scale,
+                       total, losses);
+    MMREC_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int mmrec_bpr_multi_bwd_f32(const float* U, const int64_t* users, const float* const* I, const int64_t* const* pos,
+                                       const int64_t* const* neg, const float* w, int32_t n_terms, int32_t batch, int32_t d,
+                                       const float* coef, const float* grad_scalar, float scale, float* dU, float* const* dI,
+                                       mmrec_stream_t stream) {
+    if (d <= 0 || d % MMREC_EMB_DIM) return MMREC_ERR_UNSUPPORTED;
+    if (batch < 0) return MMREC_ERR_BAD_ARG;
+    BprTerms a;
+    if (int err = bpr_terms(a, I, pos, neg, w, dI, n_terms, batch)) return err;
+    if (batch == 0) return 0;
+    if (!U || !users || !coef || !grad_scalar) return MMREC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bpr_multi_bwd_kernel, dim3((batch + 15) / 16, n_terms), dim3(256), 0, mmrec_stream(stream), U, users, a, batch,
+                       d / 4, coef, grad_scalar, scale, dU);
     MMREC_RETURN_LAUNCH_STATUS();
 }
 

@@ -873,6 +873,90 @@ class _BprLossShared(torch.autograd.Function):
         return (dU, None, None, None, None, None, None) + tuple(out)
 
 
+class _BprWeightedTotal(torch.autograd.Function):
+    """sum_t w_t bpr_loss(U, I_t, users, pos_t, neg_t): mmrec_bpr_multi_fwd_f32 / _bwd_f32 (ABI 14) -- every term's per-sample
+    work in ONE launch (grid.y = term), one finish launch for the weighted total, one backward launch.  Inputs: U, users, variant,
+    scale, weights (tuple), joint, then I_0, pos_0, neg_0, I_1, ...; `joint`: the gradients of U and of the first table are
+    adjacent row blocks of one zero-filled buffer (what lightgcn_mean_parts' backward takes copy-free)."""
+
+    @staticmethod
+    def forward(ctx, U, users, variant, scale, weights, joint, *flat):
+        lib = _lib.load()
+        n = len(weights)
+        U = _chk(U.contiguous(), torch.float32, "U", 2)
+        _chk(users, torch.int64, "users", 1)
+        B, d, dev = users.numel(), U.shape[1], U.device
+        tables = [_chk(flat[3 * t].contiguous(), torch.float32, "I", 2) for t in range(n)]
+        pos, neg = [flat[3 * t + 1] for t in range(n)], [flat[3 * t + 2] for t in range(n)]
+        for t in range(n):
+            _chk(pos[t], torch.int64, "pos", 1), _chk(neg[t], torch.int64, "neg", 1)
+            if tables[t].shape[1] != d or d % EMB_DIM or pos[t].numel() != B or neg[t].numel() != B:
+                raise _lib.MMRecHipError("U and every table need the same row width (a multiple of %d), every id list B entries" % EMB_DIM)
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ctx.arrays = (ptrs(tables), ptrs(pos), ptrs(neg), (ctypes.c_float * n)(*[float(w) for w in weights]))
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(n, max(B, 1), dtype=torch.float32, device=dev)
+        ws = _ws(lib.mmrec_bpr_multi_workspace_bytes(n, B), dev)
+        _lib.check(lib.mmrec_bpr_multi_fwd_f32(_p(U), _p(users), *ctx.arrays, n, B, d, int(variant), float(scale), _p(total), None,
+                                               _p(coef), _p(ws), _stream()), "bpr_multi_fwd")
+        ctx.save_for_backward(U, users, coef, *tables, *pos, *neg)
+        ctx.n, ctx.scale, ctx.joint = n, float(scale), bool(joint)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        n = ctx.n
+        U, users, coef = ctx.saved_tensors[:3]
+        tables = ctx.saved_tensors[3:3 + n]
+        g = g.contiguous().to(torch.float32)
+        need_u = ctx.needs_input_grad[0]
+        need_i = [ctx.needs_input_grad[6 + 3 * t] for t in range(n)]
+        dU = None
+        grads = [None] * n
+        if ctx.joint and need_u and need_i[0]:
+            both = torch.zeros((U.shape[0] + tables[0].shape[0], U.shape[1]), dtype=U.dtype, device=U.device)
+            dU, grads[0] = both[:U.shape[0]], both[U.shape[0]:]
+        elif need_u:
+            dU = torch.zeros_like(U)
+        shared = {}
+        for t in range(n):
+            if need_i[t] and grads[t] is None:
+                key = tables[t].data_ptr()
+                if key not in shared:
+                    shared[key] = torch.zeros_like(tables[t])
+                grads[t] = shared[key]
+        dI = (ctypes.c_void_p * n)(*[None if x is None else x.data_ptr() for x in grads])
+        _lib.check(lib.mmrec_bpr_multi_bwd_f32(_p(U), _p(users), *ctx.arrays, n, users.numel(), U.shape[1], _p(coef), _p(g), ctx.scale,
+                                               _p(dU), dI, _stream()), "bpr_multi_bwd")
+        out, seen = [dU, None, None, None, None, None], set()
+        for t in range(n):
+            gi = grads[t]
+            if gi is not None and id(gi) in seen:
+                gi = None                                  # (a table named by two terms: its one buffer goes to the first)
+            elif gi is not None:
+                seen.add(id(gi))
+            out += [gi, None, None]
+        return tuple(out)
+
+
+def bpr_weighted_total(U, users, terms, weights, variant=BPR_LOGSIG, reduction="mean", joint_grad=False):
+    """sum_t weights[t] * bpr_loss(U, I_t, users, pos_t, neg_t) as ONE scalar (freedom.py:197-211: the id term + reg_weight times
+    the modality terms) -- two launches forward, one backward (ABI 14); `hip_deterministic` or more than MMREC_BPR_MAX_TERMS terms:
+    the per-term form."""
+    terms = list(terms)
+    if DETERMINISTIC or not 1 <= len(terms) <= 4:
+        losses = bpr_losses_shared_users(U, users, terms, variant, reduction, joint_grad=joint_grad)
+        total = 0.0
+        for w, l in zip(weights, losses):
+            total = total + w * l
+        return total
+    B = users.numel()
+    scale = 1.0 / max(B, 1) if reduction == "mean" else 1.0
+    flat = [x for term in terms for x in term]
+    return _BprWeightedTotal.apply(U, users, variant, scale, tuple(float(w) for w in weights), joint_grad, *flat)
+
+
 def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean", joint_grad=False, sum_over_ranks=None):
     """[bpr_loss(U, I_t, users, pos_t, neg_t) for (I_t, pos_t, neg_t) in terms] with one shared gradient buffer for U;
     joint_grad: the gradient of the FIRST term's table is the row block right after U's in the same buffer.

@@ -182,8 +182,9 @@ class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRe
             # feature row only, so projecting the <= 2B gathered rows is the same function and the same
             # gradient (dW, db, and dX scattered back into the table): 2.1 GFLOP regardless of n_items
             # instead of 3.7 (Baby) / 9.6 (Sports) / 262 (500K items).
-            return _combine(hip_ops.bpr_losses_shared_users(ua, users, self._batch_terms(ia, pos_items, neg_items, rows),
-                                                            joint_grad=True), self.t_feat is not None, self.reg_weight)
+            terms = self._batch_terms(ia, pos_items, neg_items, rows)
+            # bpr(id) + reg_weight (bpr(text) + bpr(image)) (freedom.py:211): all terms in one launch pair (ABI 14)
+            return hip_ops.bpr_weighted_total(ua, users, terms, [1.0] + [self.reg_weight] * (len(terms) - 1), joint_grad=True)
         loss = hip_ops.bpr_loss(ua, ia, users, pos_items, neg_items)
         mf_t = mf_v = 0.0
         if self.t_feat is not None:
@@ -223,8 +224,8 @@ class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRe
         self.build_item_graph = False
         ia_rows = hip_ops.spmm_rows(self.mm_adj, self.item_id_embedding.weight, rows, Z_rows=at[b:])
         ar = torch.arange(b, device=rows.device)
-        return _combine(hip_ops.bpr_losses_shared_users(at[:b], ar, self._batch_terms(ia_rows, ar, ar + b, rows)),
-                        self.t_feat is not None, self.reg_weight)
+        terms = self._batch_terms(ia_rows, ar, ar + b, rows)
+        return hip_ops.bpr_weighted_total(at[:b], ar, terms, [1.0] + [self.reg_weight] * (len(terms) - 1))
 
 
 def _batch_rows_wanted(config, n_nodes):

@@ -204,6 +204,14 @@ def bpr_losses_shared_users(U, users, terms, variant=BPR_LOGSIG, reduction="mean
     return tuple(out)
 
 
+def bpr_weighted_total(U, users, terms, weights, variant=BPR_LOGSIG, reduction="mean", joint_grad=False):
+    """hip_ops.bpr_weighted_total: sum_t w_t bpr_loss(U, I_t, users, pos_t, neg_t)"""
+    total = 0.0
+    for w, (I, pos, neg) in zip(weights, terms):
+        total = total + w * bpr_loss(U, I, users, pos, neg, variant, reduction)
+    return total
+
+
 def infonce(E1, E2, ids, tau):
     _mat(E1, "E1", width=EMB_DIM), _mat(E2, "E2", width=EMB_DIM), _ids(ids, "ids")
     assert E1.shape == E2.shape
@@ -350,7 +358,7 @@ def spmm_vals(dyn, X, vals):
 
 _PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
-            "bpr_losses_shared_users", "infonce",
+            "bpr_losses_shared_users", "bpr_weighted_total", "infonce",
             "gather_sqnorm", "rows_reg", "cat_leaky", "row_normalize", "cosine_mean", "cosine_means", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
             "bipartite_graph_from_edges", "DynGraph", "spmm_vals")
 

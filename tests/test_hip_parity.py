@@ -754,6 +754,39 @@ def test_cosine_mean_fwd_bwd_vs_torch(ops, dev):
             close(Xd.grad, 3.0 * Xc.grad, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_bpr_weighted_total_fused_terms(ops, dev, variant):
+    """ABI 14 mmrec_bpr_multi_fwd/bwd_f32 (hip_ops.bpr_weighted_total): FREEDOM's bpr(id) + reg_weight (bpr(text) + bpr(image))
+    (freedom.py:197-211) as one launch pair against the per-term op: value to fp32 rounding, gradients of the user table and of
+    every term's table (one of them named twice: one buffer), duplicate ids, a batch that is no multiple of 16, both loss
+    variants, mean and sum reductions, an upstream gradient != 1, a table without gradient."""
+    g = torch.Generator().manual_seed(31 + variant)
+    nU, nI, B, d = 80, 55, 203, 64
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.3
+    U0, I0, T0, V0 = mk(nU, d), mk(nI, d), mk(2 * B, d), mk(2 * B, d)
+    users, pos, neg = (torch.randint(0, nU, (B,), generator=g), torch.randint(0, nI, (B,), generator=g),
+                       torch.randint(0, nI, (B,), generator=g))
+    users[:30] = users[30:60]
+    lp, ln = torch.arange(B), torch.arange(B) + B
+    w = [1.0, 0.13, 0.13, 0.5]
+    for reduction in ("mean", "sum"):
+        res = []
+        for fused in (True, False):
+            U, I, T = (x.clone().to(dev).requires_grad_() for x in (U0, I0, T0))
+            V = V0.clone().to(dev)                                    # no gradient for this one
+            terms = [(I, pos.to(dev), neg.to(dev)), (T, lp.to(dev), ln.to(dev)), (V, lp.to(dev), ln.to(dev)),
+                     (I, neg.to(dev), pos.to(dev))]
+            if fused:
+                out = ops.bpr_weighted_total(U, users.to(dev), terms, w, variant, reduction)
+            else:
+                out = sum(wt * l for wt, l in zip(w, ops.bpr_losses_shared_users(U, users.to(dev), terms, variant, reduction)))
+            (1.9 * out).backward()
+            res.append((out.detach(), U.grad.clone(), I.grad.clone(), T.grad.clone()))
+        close(res[0][0], res[1][0], rtol=2e-6)
+        for a, b in zip(res[0][1:], res[1][1:]):
+            close(a, b, rtol=1e-5, atol=1e-7 * (B if reduction == "sum" else 1))
+
+
 def test_cosine_means_fused_terms(ops, dev):
     """ABI 14 mmrec_cosine_multi_fwd/bwd_f32 (hip_ops.cosine_means): BM3's six BYOL terms (bm3.py:129-144) as one launch pair --
     sum_t w_t mean_b cos(X_t[ix_t[b]], Y_t[iy_t[b]]) against torch: value and gradients; indexed and un-indexed operands, an X
