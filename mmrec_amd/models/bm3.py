@@ -133,16 +133,21 @@ class BM3(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecomm
         # six BYOL terms 1 - mean cos(online, detached target): each ONE fused gather-dot-norm kernel (+ one scatter
         # kernel backward) instead of ~20 elementwise / reduction launches (bm3.py:129-144)
         # (round 6: ALL of them in one launch pair -- hip_ops.cosine_means, ABI 14 -- as const - sum_t w_t mean cos_t)
-        u_pred, i_pred = self._predict(u_ori), self._predict(i_ori)
+        # the ONE predictor (bm3.py:61,129-135: self.predictor on u, i, t, v) applied to the row-wise cat of its inputs: one
+        # forward and one backward instead of four each, and no sums of four weight / bias gradients (rows are independent:
+        # the same values)
+        online = [u_ori, i_ori] + [x for x in (t_on, v_on) if x is not None]
+        preds = list(self._predict(torch.cat(online, 0)).split([x.shape[0] for x in online]))
+        u_pred, i_pred = preds.pop(0), preds.pop(0)
         cl = float(self.cl_weight)
         terms, const = [(u_pred, users, i_tgt, items, -1.0), (i_pred, items, u_tgt, users, -1.0)], 2.0      # loss_ui, loss_iu
         if t_on is not None:
-            t_pred, t_idx = self._predict(t_on), (None if lazy else items)
+            t_pred, t_idx = preds.pop(0), (None if lazy else items)
             t_tgt = t_on.detach() * t_tgt[items_ds, :] if lazy else t_tgt
             terms += [(t_pred, t_idx, i_tgt, items, -cl), (t_pred, t_idx, t_tgt, t_idx, -cl)]                # loss_t, loss_tv
             const += 2.0 * cl
         if v_on is not None:
-            v_pred, v_idx = self._predict(v_on), (None if lazy else items)
+            v_pred, v_idx = preds.pop(0), (None if lazy else items)
             v_tgt = v_on.detach() * v_tgt[items_ds, :] if lazy else v_tgt
             terms += [(v_pred, v_idx, i_tgt, items, -cl), (v_pred, v_idx, v_tgt, v_idx, -cl)]                # loss_v, loss_vt
             const += 2.0 * cl
