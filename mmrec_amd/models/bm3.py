@@ -82,18 +82,19 @@ class BM3(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRecomm
         return self._predict(u.contiguous()), self._predict(i.contiguous())
 
     def _targets(self, *tensors, sides=None):
-        """dropout(clone) targets without gradient; one F.dropout call per tensor, in the
+        """dropout(clone) targets without gradient (bm3.py:107-122; F.dropout is out of place, so the reference's clone is not
+        repeated: four D2D copies per step); one F.dropout call per tensor, in the
         reference's order (u, i, t, v) so an injected dropout function replays the same masks.  Under `reorder` a mask is
         drawn for the rows in the DATASET's order (the plain model's draw, element for element) and carried to the relabelled
         rows: sides[j] = 'u' / 'i' names tensor j's id space, None = rows already in dataset order."""
         rl = self.relabelling
         with torch.no_grad():
             if rl is None:
-                return [F.dropout(t.detach().clone(), self.dropout) for t in tensors]
+                return [F.dropout(t.detach(), self.dropout) for t in tensors]
             out = []
             for t, side in zip(tensors, sides):
                 if side is None:
-                    out.append(F.dropout(t.detach().clone(), self.dropout))
+                    out.append(F.dropout(t.detach(), self.dropout))
                     continue
                 perm, inv = (rl.perm_u, rl.inv_u) if side == 'u' else (rl.perm_i, rl.inv_i)
                 out.append(F.dropout(t.detach().index_select(0, perm), self.dropout).index_select(0, inv))
