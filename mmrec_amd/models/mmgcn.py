@@ -178,9 +178,15 @@ class MMGCN(RelabelledIdsMixin, FusedEvalMixin, GeneralRecommender):
         out = self.forward()
         # interleaved (pos, neg) pairs == BPR with -mean log sigmoid(pos - neg): the fused kernel on one table
         loss = hip_ops.bpr_loss(out, out, users, pos.contiguous(), neg.contiguous(), hip_ops.BPR_LOGSIG, 'mean')
-        user_t = users.repeat_interleave(2)
-        item_t = torch.stack((pos, neg)).t().contiguous().view(-1)
-        reg = (self.id_embedding[user_t] ** 2 + self.id_embedding[item_t] ** 2).mean()
+        # reg = (id[user_t] ** 2 + id[item_t] ** 2).mean() over the interleaved [2B, 64] rows (+ mean(preference ** 2)), mmgcn.py:
+        # 118-124: (2 sum ||id[u]||^2 + sum ||id[p]||^2 + sum ||id[n]||^2) / (2 B 64) -- neither id_embedding nor preference is a
+        # Parameter there (or here), so the term only shifts the reported loss: one fused pass over the batch rows, the
+        # preference mean computed once
+        e = self.id_embedding
+        reg = hip_ops.rows_reg(((e, users), (e, users), (e, pos), (e, neg)), hip_ops.ROWS_REG_SQUARED,
+                               self.reg_weight / (2.0 * users.shape[0] * e.shape[1]))
         if self.v_feat is not None:
-            reg = reg + (self.v_gcn.preference ** 2).mean()
-        return loss + self.reg_weight * reg
+            if getattr(self, '_pref_sq_mean', None) is None or self._pref_sq_mean[0] is not self.v_gcn.preference:
+                self._pref_sq_mean = (self.v_gcn.preference, float((self.v_gcn.preference ** 2).mean()) * self.reg_weight)
+            return loss + reg + self._pref_sq_mean[1]
+        return loss + reg
