@@ -637,6 +637,54 @@ class _LightGCNMeanPartsRows(torch.autograd.Function):
         return (None, None, None) + tuple(t.split(ctx.sizes))
 
 
+class _MeanPartsRowsThenItemRows(torch.autograd.Function):
+    """FREEDOM's training-step forward at the batch rows as ONE autograd node: at = lightgcn_mean_parts_rows(g, (user table, item
+    table), L, cat(users, nu + item_rows)), then ia = (mm @ item table)[item_rows] + at[b:] (freedom.py:165-178 read at
+    :197-199).  As two nodes the item table receives two dense gradients -- the propagation's block and a zero-filled
+    [n_items, d] buffer the item-item layer's backward pushes into -- that autograd then adds: at config 5 a 128 MB fill and a
+    384 MB add per step (17 + 60 us of a 2.1 ms step).  Here the push goes straight into the propagation's gradient.
+    Inputs: g, n_layers, rows, mm, item_rows, n_user_rows (b), then the two tables.  Forward bits: the two ops'."""
+
+    @staticmethod
+    def forward(ctx, g, n_layers, rows, mm, item_rows, b, user_table, item_table):
+        import types
+        inner = types.SimpleNamespace(saved=None)
+        inner.save_for_backward = lambda *t: setattr(inner, 'saved', t)
+        at = _LightGCNMeanPartsRows.forward(inner, g, n_layers, rows, user_table, item_table)
+        ia = spmm_rows_raw(mm, item_table.detach().contiguous(), item_rows, at[b:].contiguous(), z_compact=True)
+        ctx.inner = types.SimpleNamespace(sizes=inner.sizes, g=inner.g, L=inner.L)
+        ctx.mm, ctx.b = mm, int(b)
+        ctx.save_for_backward(rows, item_rows)
+        return at[:b].contiguous(), ia
+
+    @staticmethod
+    def backward(ctx, d_user_rows, d_ia):
+        rows, item_rows = ctx.saved_tensors
+        inner = ctx.inner
+        inner.saved_tensors = (rows,)
+        d_ia = d_ia.contiguous()
+        d_rows = torch.cat((d_user_rows.contiguous(), d_ia), dim=0)        # d at = (d user rows, d ia: Z passes its gradient on)
+        grads = _LightGCNMeanPartsRows.backward(inner, d_rows)
+        d_user_table, d_item_table = grads[3], grads[4]
+        spmm_push_rows_raw(ctx.mm, d_ia, item_rows, dX=d_item_table)       # (atomics into the propagation's item block)
+        return None, None, None, None, None, None, d_user_table, d_item_table
+
+
+def lightgcn_mean_rows_then_item_rows(g: CsrGraph, user_table, item_table, n_layers, users, item_rows, mm: CsrGraph):
+    """-> (propagated user rows [b, d], (mm @ item_table)[item_rows] + propagated item rows [len(item_rows), d]) for a training
+    step that reads its tables at the batch rows only; one autograd node when every piece has its row-list kernel, the two
+    ops otherwise (`hip_deterministic`, relabelled graphs, rows spanning too many chunks)."""
+    b, nu, d = users.shape[0], user_table.shape[0], user_table.shape[1]
+    rows = torch.cat((users, item_rows + nu))
+    fast = (not DETERMINISTIC and not isinstance(g, PermutedGraph) and not isinstance(mm, PermutedGraph) and d == EMB_DIM
+            and int(n_layers) >= 1 and ROWS_LAST_LAYER and rows_servable(g, d) and rows_servable(mm, d)
+            and user_table.shape[0] + item_table.shape[0] == g.n_rows == g.n_cols and mm.n_rows == mm.n_cols == item_table.shape[0])
+    if not fast:
+        at = lightgcn_mean_parts_rows(g, (user_table, item_table), n_layers, rows)
+        return at[:b], spmm_rows(mm, item_table, item_rows, Z_rows=at[b:])
+    return _MeanPartsRowsThenItemRows.apply(g, n_layers, rows, mm, item_rows, b, user_table, item_table)
+
+
 def lightgcn_mean_parts_rows(g: CsrGraph, parts, n_layers, rows):
     """lightgcn_mean_parts(g, parts, n_layers) read at `rows` (int64 ids in the concatenated id space) -> [len(rows), d];
     same forward bits, the backward starts from the compact gradient (see the class).  `hip_deterministic`: the dense path."""

@@ -218,14 +218,16 @@ class FREEDOM(RelabelledIdsMixin, AdjacentTablesMixin, FusedEvalMixin, GeneralRe
             (hip_ops.lightgcn_mean_parts_rows): the dense [N, 64] gradient of the mean and the first of the backward's
             launches over all rows go away.
         Forward values are bit-identical to the full computation; the backward's pushes use fp32 atomics."""
-        b, nu = users.shape[0], self.n_users
-        at = hip_ops.lightgcn_mean_parts_rows(self.masked_adj, (self.user_embedding.weight, self.item_id_embedding.weight),
-                                              self.n_ui_layers, torch.cat((users, rows + nu)))
+        b = users.shape[0]
+        # (one autograd node: the item-item layer's backward pushes into the propagation's gradient of the item table instead
+        #  of a zero-filled [n_items, 64] buffer of its own that autograd would add -- 128 MB + 384 MB of traffic at config 5)
+        ua_rows, ia_rows = hip_ops.lightgcn_mean_rows_then_item_rows(self.masked_adj, self.user_embedding.weight,
+                                                                     self.item_id_embedding.weight, self.n_ui_layers, users, rows,
+                                                                     self.mm_adj)
         self.build_item_graph = False
-        ia_rows = hip_ops.spmm_rows(self.mm_adj, self.item_id_embedding.weight, rows, Z_rows=at[b:])
         ar = torch.arange(b, device=rows.device)
         terms = self._batch_terms(ia_rows, ar, ar + b, rows)
-        return hip_ops.bpr_weighted_total(at[:b], ar, terms, [1.0] + [self.reg_weight] * (len(terms) - 1))
+        return hip_ops.bpr_weighted_total(ua_rows, ar, terms, [1.0] + [self.reg_weight] * (len(terms) - 1))
 
 
 def _batch_rows_wanted(config, n_nodes):

@@ -231,6 +231,12 @@ def cosine_mean(X, ix, Y, iy):
     return F.cosine_similarity(x, y, dim=-1).mean()
 
 
+def lightgcn_mean_rows_then_item_rows(g, user_table, item_table, n_layers, users, item_rows, mm):
+    b, nu = users.shape[0], user_table.shape[0]
+    at = lightgcn_mean_parts_rows(g, (user_table, item_table), n_layers, torch.cat((users, item_rows + nu)))
+    return at[:b], spmm_rows(mm, item_table, item_rows, Z_rows=at[b:])
+
+
 def cosine_means(terms):
     """hip_ops.cosine_means: sum_t w_t mean cos(X_t[ix_t], Y_t[iy_t])"""
     total = 0.0
@@ -356,7 +362,7 @@ def spmm_vals(dyn, X, vals):
     return out.index_add(0, dyn.rows, vals.unsqueeze(1) * X[dyn.cols])
 
 
-_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "layergcn_sum", "layergcn_sum_parts",
+_PATCHED = ("CsrGraph", "spmm_raw", "spmm", "spmm_rows", "lightgcn_mean", "lightgcn_mean_parts", "lightgcn_mean_parts_rows", "lightgcn_mean_rows_then_item_rows", "layergcn_sum", "layergcn_sum_parts",
             "bpr_loss",
             "bpr_losses_shared_users", "bpr_weighted_total", "infonce",
             "gather_sqnorm", "rows_reg", "cat_leaky", "row_normalize", "cosine_mean", "cosine_means", "linear", "score_topk", "topk_hint_served", "topk_hint_width", "TopkCandidates", "degree_count", "edge_norm_values",
