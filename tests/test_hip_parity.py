@@ -1978,7 +1978,10 @@ def test_sharded_freedom_plugin_rccl_single_rank(tmp_path, golden, dev, layout):
         np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-5)
         assert res[True][1] == res[False][1]
         for name, ref in res[False][2].items():
-            atol = 1e-4 if name.endswith("trs.bias") else 1e-6       # analytically-zero gradient: Adam-normalised noise
+            # analytically-zero gradient (the biases): Adam-normalised noise; elsewhere the same noise on single elements whose
+            # gradient nearly cancels -- the two runs sum the batch's duplicates by atomics in different launch shapes: one
+            # element of 12,800 at 1.1e-5 (3.2e-4 relative) was observed (round 6)
+            atol = 1e-4 if name.endswith("trs.bias") else 2e-5
             np.testing.assert_allclose(res[True][2][name].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=atol, err_msg=name)
     finally:
         dist.destroy_process_group()

@@ -471,8 +471,12 @@ def test_graphed_train_step_equals_eager(tmp_path, golden, name, extra):
         results.append((total, [p.detach().cpu().numpy().copy() for p in model.parameters()]))
     (t0, p0), (t1, p1) = results
     np.testing.assert_allclose(t1, t0, rtol=1e-5)
+    # MMGCN: ~300 launches per step, the BPR scatter's atomics feed 14 projections and 6 aggregations -- an element whose gradient
+    # is rounding noise moves by up to lr per step in a direction the summation order decides (Adam normalises it): 6.6e-6 on
+    # 46 of 24,576 elements was observed between two runs of the SAME launches (round 6); 2e-5 = two such steps
+    atol = 2e-5 if name == "MMGCN" else 1e-6
     for a, b in zip(p0, p1):
-        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=atol)
 
 
 def test_mmgcn_model(tmp_path, golden):
