@@ -454,7 +454,11 @@ def test_graphed_train_step_equals_eager(tmp_path, golden, name, extra):
     (same kernels in the same order; fp32 atomics in the BPR scatter allow last-ulp differences)."""
     from mmrec_amd.common.trainer import Trainer
     results = []
-    for graphed in (False, True):
+    # MMGCN on the golden dataset has a 40-wide modality whose x @ W goes through the library GEMM (torch.matmul): the FIRST such
+    # call of a process can take another algorithm than the later ones (measured, round 6: the first eager run of a process differed
+    # from BOTH the graphed and a second eager run by 1.6e-4 in one 64 x 64 weight, the latter two agreed to 3e-7) -- a discarded
+    # warm-up run settles it before the two runs that are compared
+    for graphed in ((False, False, True) if name == "MMGCN" else (False, True)):
         config, train_data, _, model = build(tmp_path, golden, name, dict(extra, hip_graph_step=graphed))
         config["hip_graph_step"] = graphed
         torch.manual_seed(123)
@@ -469,7 +473,7 @@ def test_graphed_train_step_equals_eager(tmp_path, golden, name, extra):
         from mmrec_amd.common.lazy_rows import flush_lazy_tables
         flush_lazy_tables(model)      # the eager FREEDOM run uses the row-lazy Adam (automatic): apply what is postponed
         results.append((total, [p.detach().cpu().numpy().copy() for p in model.parameters()]))
-    (t0, p0), (t1, p1) = results
+    (t0, p0), (t1, p1) = results[-2:]
     np.testing.assert_allclose(t1, t0, rtol=1e-5)
     # MMGCN: ~300 launches per step, the BPR scatter's atomics feed 14 projections and 6 aggregations -- an element whose gradient
     # is rounding noise moves by up to lr per step in a direction the summation order decides (Adam normalises it): 6.6e-6 on
